@@ -1,0 +1,79 @@
+"""In-tree build of the native parts (gfx950 only).
+
+  libpvnet_vote.so   HIP kernels + C ABI (include/pvnet_vote.h), hipcc, no torch
+  ransac_voting.so   pybind11/torch shim over that C ABI, host compiler only
+
+Both land next to this file so they travel with the source tree (a JIT cache
+under ~/.cache would not).  hipcc cross-compiles for gfx950 without a GPU.
+"""
+import os
+import shutil
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+INCLUDE = os.path.join(ROOT, "include")
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpvnet_vote.so")
+EXT = os.path.join(HERE, "ransac_voting.so")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+# -ffp-contract=off is part of the numerical contract (bit-exact inlier counts), not a tuning flag.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target, *sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build_lib(force=False, verbose=False):
+    src = os.path.join(CSRC, "pvnet_vote.hip")
+    hdr = os.path.join(INCLUDE, "pvnet_vote.h")
+    if not force and _newer(LIB, src, hdr):
+        return LIB
+    hipcc = shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
+    _run([hipcc, *HIPCC_FLAGS, "-I" + INCLUDE, "-o", LIB, src], verbose)
+    return LIB
+
+
+def build_ext(force=False, verbose=False):
+    src = os.path.join(CSRC, "ransac_voting_ext.cpp")
+    hdr = os.path.join(INCLUDE, "pvnet_vote.h")
+    build_lib(verbose=verbose)
+    if not force and _newer(EXT, src, hdr, LIB):
+        return EXT
+    import torch
+    from torch.utils import cpp_extension as ce
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    inc = [*ce.include_paths(), sysconfig.get_paths()["include"], INCLUDE, os.path.join(ROCM, "include")]
+    cxx = os.environ.get("CXX", "g++")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-deprecated-declarations",
+           "-DTORCH_EXTENSION_NAME=ransac_voting", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ["-I" + p for p in inc]
+    cmd += [src, "-o", EXT, "-L" + HERE, "-lpvnet_vote", "-L" + tlib, "-lc10", "-lc10_hip", "-ltorch_cpu",
+            "-ltorch_hip", "-ltorch", "-ltorch_python", "-L" + os.path.join(ROCM, "lib"), "-lamdhip64",
+            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib, "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+    _run(cmd, verbose)
+    return EXT
+
+
+def build_all(force=False, verbose=False):
+    return build_lib(force, verbose), build_ext(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,1112 @@
+// pvnet_vote.hip -- RANSAC voting hot path of clean-pvnet as native HIP for gfx950 (MI355X).
+//
+// Written for CDNA4 only: 64-lane wavefronts are assumed everywhere (ballot masks are 64 bit,
+// lane broadcasts use v_readlane), there is no CUDA path and no CPU fallback.
+//
+// Arithmetic contract (see oracle/vote_oracle.c): the inlier decision and the hypothesis
+// intersection are IEEE binary32 with one rounding per source-level operation and NO fused
+// multiply-add, so inlier counts are bit-exact against the oracle.  This file must be built
+// with -ffp-contract=off; the pragma below enforces it even if the flag is forgotten.
+//
+// Reference behaviour restated (paths relative to /root/reference):
+//   K = lib/csrc/ransac_voting/src/ransac_voting_kernel.cu
+//   P = lib/csrc/ransac_voting/ransac_voting_gpu.py
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "pvnet_vote.h"
+
+#pragma clang fp contract(off)
+
+#define PVV_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+constexpr int kBlock = 256;          // 4 wavefronts
+constexpr int kTileSteps = 8;
+constexpr int kTile = kBlock * kTileSteps;  // pixels per compaction tile
+constexpr int kPixPerWave = 64;      // pixels one wave walks per work item of the count kernel
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return PVV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact binary32 building blocks (shared by every kernel that takes an inlier decision).
+// ---------------------------------------------------------------------------------------------
+
+// (double)f < 1e-6  <=>  f <= fl32(1e-6): fl32(1e-6) = 9.99999997e-07 is the largest binary32
+// below the double literal of K:42-43,121.  False for NaN, like the original compare.
+__device__ __forceinline__ bool lt_1e6(float f) { return f <= 1e-6f; }
+
+// K:100-125, one (hi,vi,ti) thread.
+__device__ __forceinline__ bool vote_exact(float cx, float cy, float hx, float hy, float nx,
+                                           float ny, float thresh)
+{
+    float dx = hx - cx;
+    float dy = hy - cy;
+    float norm1 = sqrtf(nx * nx + ny * ny);
+    float norm2 = sqrtf(dx * dx + dy * dy);
+    if (lt_1e6(norm1) || lt_1e6(norm2)) return false;
+    float angle_dist = (dx * nx + dy * ny) / (norm1 * norm2);
+    return angle_dist > thresh;
+}
+
+// K:22-48, one (hi,vi) thread; (0,0) when degenerate (K:42-43 + at::zeros K:75).
+__device__ __forceinline__ float2 hypothesis_exact(float dx0, float dy0, float cx0, float cy0,
+                                                   float dx1, float dy1, float cx1, float cy1)
+{
+    float nx0 = dy0, ny0 = -dx0;
+    float nx1 = dy1, ny1 = -dx1;
+    float den_y = nx1 * ny0 - nx0 * ny1;
+    float den_x = ny1 * nx0 - ny0 * nx1;
+    if (lt_1e6(fabsf(den_y))) return make_float2(0.f, 0.f);
+    if (lt_1e6(fabsf(den_x))) return make_float2(0.f, 0.f);
+    float y = (nx1 * (nx0 * cx0 + ny0 * cy0) - nx0 * (nx1 * cx1 + ny1 * cy1)) / den_y;
+    float x = (ny1 * (nx0 * cx0 + ny0 * cy0) - ny0 * (nx1 * cx1 + ny1 * cy1)) / den_x;
+    return make_float2(x, y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 / block helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+__device__ __forceinline__ float bcast(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum over the 256-thread block; result valid in every thread.  `red` holds >= 4 T.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T *red)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane_id() == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// Counter-based RNG: splitmix64 finaliser over (seed, stream, a, b).  Used when no
+// idxs / selection tensors are injected; statistical parity with torch's Philox only.
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint32_t stream, uint32_t a, uint32_t b)
+{
+    uint64_t k = mix64(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(stream + 1));
+    return (uint32_t)(mix64(k ^ (((uint64_t)a << 32) | b)) >> 32);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 1: foreground compaction (replaces sum / nonzero / masked_select / uniform_ of
+// P:125-144 and P:207-229), order = row-major order of torch.nonzero.
+// ---------------------------------------------------------------------------------------------
+struct MaskArgs {
+    const void *mask;
+    const float *selection;  // [B,H,W] injected U(0,1) or nullptr
+    int64_t sb, sh, sw;      // element strides
+    int es;                  // element size in bytes
+    int contig;              // sh == W && sw == 1
+    int mode;                // 0: v3 (low byte != 0, weight = low byte)  1: estimate (== 1)
+    int W, HW, T;
+    int min_num, max_num, cap;
+    uint64_t seed;
+};
+
+template <int ES>
+__device__ __forceinline__ uint64_t load_elem(const void *base, int64_t off)
+{
+    if (ES == 1) return ((const uint8_t *)base)[off];
+    if (ES == 2) return ((const uint16_t *)base)[off];
+    if (ES == 4) return ((const uint32_t *)base)[off];
+    return ((const uint64_t *)base)[off];
+}
+
+// weight of pixel p of image b: 0 = background; v3: low byte (P:125-126 sums the bytes),
+// estimate: 1 (P:207-208).
+template <int ES>
+__device__ __forceinline__ int mask_weight(const MaskArgs &a, int b, int p)
+{
+    int64_t off;
+    if (a.contig) {
+        off = (int64_t)b * a.sb + p;
+    } else {
+        int y = p / a.W;
+        int x = p - y * a.W;
+        off = (int64_t)b * a.sb + (int64_t)y * a.sh + (int64_t)x * a.sw;
+    }
+    uint64_t v = load_elem<ES>(a.mask, off);
+    if (a.mode == 0) return (int)(v & 0xFF);
+    return v == 1 ? 1 : 0;
+}
+
+// U(0,1) draw of P:136 / P:220 for pixel p of image b.
+__device__ __forceinline__ float selection_draw(const MaskArgs &a, int b, int p)
+{
+    if (a.selection) return a.selection[(int64_t)b * a.HW + p];
+    return (float)(rng_u32(a.seed, 0u, (uint32_t)b, (uint32_t)p) >> 8) * 0x1p-24f;
+}
+
+template <int ES>
+__global__ __launch_bounds__(kBlock) void k_tile_count(MaskArgs a, int *__restrict__ tile_nz,
+                                                       int *__restrict__ tile_sum)
+{
+    __shared__ int red[4];
+    const int t = blockIdx.x, b = blockIdx.y;
+    int nz = 0, sum = 0;
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s) {
+        int p = t * kTile + s * kBlock + threadIdx.x;
+        if (p < a.HW) {
+            int w = mask_weight<ES>(a, b, p);
+            nz += (w != 0);
+            sum += w;
+        }
+    }
+    nz = block_sum(nz, red);
+    sum = block_sum(sum, red);
+    if (threadIdx.x == 0) {
+        tile_nz[b * a.T + t] = nz;
+        tile_sum[b * a.T + t] = sum;
+    }
+}
+
+// foreground_num of P:126 / P:208 from the per-tile partial sums.
+__device__ __forceinline__ long long image_fg(const int *__restrict__ tile_sum, int b, int T,
+                                              long long *red)
+{
+    long long s = 0;
+    for (int i = threadIdx.x; i < T; i += kBlock) s += tile_sum[b * T + i];
+    return block_sum(s, red);
+}
+
+// P:135-138 / P:219-223: when foreground_num > max_num every foreground pixel survives with
+// probability max_num/foreground_num (binary32 quotient).  Recount the survivors per tile.
+template <int ES>
+__global__ __launch_bounds__(kBlock) void k_tile_recount(MaskArgs a, int *__restrict__ tile_nz,
+                                                         const int *__restrict__ tile_sum)
+{
+    __shared__ long long redl[4];
+    __shared__ int red[4];
+    const int t = blockIdx.x, b = blockIdx.y;
+    long long fg = image_fg(tile_sum, b, a.T, redl);
+    if (fg <= (long long)a.max_num) return;
+    const float prob = (float)a.max_num / (float)fg;
+    int nz = 0;
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s) {
+        int p = t * kTile + s * kBlock + threadIdx.x;
+        if (p < a.HW && mask_weight<ES>(a, b, p) != 0 && selection_draw(a, b, p) < prob) ++nz;
+    }
+    nz = block_sum(nz, red);
+    if (threadIdx.x == 0) tile_nz[b * a.T + t] = nz;
+}
+
+struct VertexArgs {
+    const float *vertex;
+    int64_t sb, sh, sw, sk, sc;
+    int K;
+    int vec2;  // sc == 1 and every other stride even: (x,y) is one aligned 8-byte load
+};
+
+// Ordered scatter: pixel -> row r of the image's compacted list; writes coords[b][r] = (x,y)
+// (P:140-141) and dirs[b][vi][r] = vertex[b,y,x,vi,:] (P:142-143, stored planar per keypoint so
+// that the count kernel's loads are unit-stride).
+template <int ES>
+__global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
+                                                    const int *__restrict__ tile_nz,
+                                                    const int *__restrict__ tile_sum,
+                                                    int *__restrict__ tn_out,
+                                                    float2 *__restrict__ coords,
+                                                    float2 *__restrict__ dirs)
+{
+    __shared__ long long redl[4];
+    __shared__ int red[4];
+    __shared__ int seg[kTileSteps * 4 + 1];
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+
+    const long long fg = image_fg(tile_sum, b, a.T, redl);
+    if (fg < (long long)a.min_num) {  // P:129-132 / P:211-216: image skipped
+        if (t == 0 && threadIdx.x == 0) tn_out[b] = 0;
+        return;
+    }
+    const bool subsample = fg > (long long)a.max_num;
+    const float prob = subsample ? (float)a.max_num / (float)fg : 2.0f;
+
+    int before = 0, total = 0;
+    for (int i = threadIdx.x; i < a.T; i += kBlock) {
+        int c = tile_nz[b * a.T + i];
+        total += c;
+        if (i < t) before += c;
+    }
+    before = block_sum(before, red);
+    total = block_sum(total, red);
+    if (t == 0 && threadIdx.x == 0) tn_out[b] = total < a.cap ? total : a.cap;
+
+    unsigned keep = 0;
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s) {
+        int p = t * kTile + s * kBlock + threadIdx.x;
+        bool f = false;
+        if (p < a.HW) {
+            f = mask_weight<ES>(a, b, p) != 0;
+            if (f && subsample) f = selection_draw(a, b, p) < prob;
+        }
+        unsigned long long m = __ballot(f);
+        if (lane == 0) seg[s * 4 + wave] = __popcll(m);
+        if (f) keep |= 1u << s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // wave 0: exclusive scan of the 32 (step,wave) segment counts
+        int c = threadIdx.x < kTileSteps * 4 ? seg[threadIdx.x] : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int n = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += n;
+        }
+        if (threadIdx.x < kTileSteps * 4) seg[threadIdx.x] = inc - c;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s) {
+        bool f = (keep >> s) & 1u;
+        unsigned long long m = __ballot(f);
+        if (!f) continue;
+        int r = before + seg[s * 4 + wave] + __popcll(m & ((1ull << lane) - 1ull));
+        if (r >= a.cap) continue;
+        int p = t * kTile + s * kBlock + threadIdx.x;
+        int y = p / a.W;
+        int x = p - y * a.W;
+        coords[(size_t)b * a.cap + r] = make_float2((float)x, (float)y);
+        const float *src = v.vertex + (int64_t)b * v.sb + (int64_t)y * v.sh + (int64_t)x * v.sw;
+        for (int vi = 0; vi < v.K; ++vi) {
+            float2 d;
+            if (v.vec2) {
+                d = *(const float2 *)(src + (int64_t)vi * v.sk);
+            } else {
+                d.x = src[(int64_t)vi * v.sk];
+                d.y = src[(int64_t)vi * v.sk + v.sc];
+            }
+            dirs[((size_t)b * v.K + vi) * a.cap + r] = d;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2: hypotheses (replaces random_ P:145/P:235 + generate_hypothesis K:11-86), and zeroes
+// the inlier counters of the same (b,vi,hi).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_gen_hypothesis(
+    const int32_t *__restrict__ idxs /*[B,hn,K,2] or null*/, const int *__restrict__ tn_arr,
+    const float2 *__restrict__ coords, const float2 *__restrict__ dirs, float2 *__restrict__ hyps,
+    int *__restrict__ counts, int B, int K, int hn, int cap, uint64_t seed)
+{
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (long long)B * K * hn) return;
+    const int hi = (int)(gid % hn);
+    const int vi = (int)((gid / hn) % K);
+    const int b = (int)(gid / ((long long)hn * K));
+    counts[gid] = 0;
+    const int tn = tn_arr[b];
+    if (tn <= 0) {
+        hyps[gid] = make_float2(0.f, 0.f);
+        return;
+    }
+    int t0, t1;
+    if (idxs) {
+        const int32_t *ip = idxs + (((size_t)b * hn + hi) * K + vi) * 2;
+        t0 = ip[0];
+        t1 = ip[1];
+        // the reference reads out of bounds here; clamp instead of faulting
+        t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);
+        t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
+    } else {
+        uint32_t c = (uint32_t)(hi * K + vi) * 2u;
+        t0 = (int)(rng_u32(seed, 1u, (uint32_t)b, c) % (uint32_t)tn);
+        t1 = (int)(rng_u32(seed, 1u, (uint32_t)b, c + 1u) % (uint32_t)tn);
+    }
+    const float2 *dp = dirs + ((size_t)b * K + vi) * cap;
+    const float2 *cp = coords + (size_t)b * cap;
+    float2 d0 = dp[t0], d1 = dp[t1], c0 = cp[t0], c1 = cp[t1];
+    hyps[gid] = hypothesis_exact(d0.x, d0.y, c0.x, c0.y, d1.x, d1.y, c1.x, c1.y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 3: inlier counting -- the hot kernel.  Replaces voting_for_hypothesis (K:88-167) +
+// torch.sum(inlier, 2) (P:159 / P:243) without the [hn,vn,tn] byte scratch.
+//
+// Mapping (wave64): LANES ARE HYPOTHESES.  Each lane keeps R hypotheses of one keypoint and their
+// R counters in VGPRs; the wave loads 64 compacted pixels with one coalesced load per array,
+// then walks them one by one, broadcasting a pixel's (cx,cy,nx,ny,norm1) to SGPRs with
+// v_readlane so that every evaluation is VGPR(hypothesis) x SGPR(pixel) arithmetic.  Counters
+// are private per lane: no cross-lane reduction in the loop; one atomicAdd per (lane, r) per
+// work item at the end (integer adds => order independent => bit-exact counts).
+//
+// Work item = (image b, keypoint vi, hypothesis tile of 64*R, pixel chunk of 4 waves x 64 px).
+// The number of items depends on tn[b], which only the device knows, so the grid is persistent
+// and every block derives the item list from tn[] itself (no host sync, no empty blocks).
+// ---------------------------------------------------------------------------------------------
+struct CountArgs {
+    const float2 *coords;  // pixel p of image b: coords[b*c_b + p]
+    const float2 *dirs;    // dirs[b*d_b + vi*d_v + p*d_p]
+    const float2 *hyps;    // hyps[b*h_b + vi*h_v + hi*h_h]
+    int *counts;           // counts[b*h_b + vi*h_v + hi*h_h]
+    const int *tn_arr;     // per image, or nullptr -> tn_fixed
+    long long c_b, d_b, d_v, d_p, h_b, h_v, h_h;
+    int tn_fixed;
+    int B, K, hn;
+    float thresh;
+};
+
+constexpr int kMaxBatchLds = 1024;  // images per launch (item prefix lives in LDS)
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_count_inliers(CountArgs a)
+{
+    __shared__ int item_end[kMaxBatchLds];  // inclusive prefix of items per image
+    const int lane = lane_id(), wave = wave_id();
+    constexpr int HT = 64 * R;
+    constexpr int PC = 4 * kPixPerWave;
+    const int nht = (a.hn + HT - 1) / HT;
+    const int per_chunk = a.K * nht;
+
+    // inclusive scan of items per image (wave 0, 64 images per step)
+    if (wave == 0) {
+        int carry = 0;
+        for (int b0 = 0; b0 < a.B; b0 += 64) {
+            int b = b0 + lane;
+            int n = 0;
+            if (b < a.B) {
+                int tn = a.tn_arr ? a.tn_arr[b] : a.tn_fixed;
+                n = ((tn + PC - 1) / PC) * per_chunk;
+            }
+            int inc = n;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int m = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += m;
+            }
+            inc += carry;
+            if (b < a.B) item_end[b] = inc;
+            carry = __builtin_amdgcn_readlane(inc, 63);
+        }
+    }
+    __syncthreads();
+    const int total = item_end[a.B - 1];
+
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        // image of this item: first b with item_end[b] > item
+        int lo = 0, hi = a.B - 1;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (item_end[mid] > item) hi = mid; else lo = mid + 1;
+        }
+        const int b = __builtin_amdgcn_readfirstlane(lo);
+        const int local = __builtin_amdgcn_readfirstlane(item - (b ? item_end[b - 1] : 0));
+        const int chunk = local / per_chunk;
+        const int rem = local - chunk * per_chunk;
+        const int vi = rem / nht;
+        const int ht = rem - vi * nht;
+        const int tn = __builtin_amdgcn_readfirstlane(a.tn_arr ? a.tn_arr[b] : a.tn_fixed);
+
+        // this lane's R hypotheses (NaN => never an inlier => padding)
+        float hx[R], hy[R];
+        int cnt[R];
+        const long long hbase = (long long)b * a.h_b + (long long)vi * a.h_v;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int h = ht * HT + r * 64 + lane;
+            float2 hp = make_float2(NAN, NAN);
+            if (h < a.hn) hp = a.hyps[hbase + (long long)h * a.h_h];
+            hx[r] = hp.x;
+            hy[r] = hp.y;
+            cnt[r] = 0;
+        }
+
+        const int p0 = chunk * PC + wave * kPixPerWave;
+        const int nvalid = min(kPixPerWave, tn - p0);  // wave-uniform
+        if (nvalid > 0) {
+            float cx = 0.f, cy = 0.f, nx = 0.f, ny = 0.f;
+            if (lane < nvalid) {
+                float2 c = a.coords[(long long)b * a.c_b + p0 + lane];
+                float2 d = a.dirs[(long long)b * a.d_b + (long long)vi * a.d_v +
+                                  (long long)(p0 + lane) * a.d_p];
+                cx = c.x; cy = c.y; nx = d.x; ny = d.y;
+            }
+            float norm1 = sqrtf(nx * nx + ny * ny);
+            if (lt_1e6(norm1)) norm1 = NAN;  // K:121 reject, folded into the quotient below
+
+            for (int j = 0; j < nvalid; ++j) {
+                const float scx = bcast(cx, j), scy = bcast(cy, j);
+                const float snx = bcast(nx, j), sny = bcast(ny, j);
+                const float sn1 = bcast(norm1, j);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float dx = hx[r] - scx;
+                    float dy = hy[r] - scy;
+                    float norm2 = sqrtf(dx * dx + dy * dy);
+                    float angle = (dx * snx + dy * sny) / (sn1 * norm2);
+                    cnt[r] += (!lt_1e6(norm2) && angle > a.thresh) ? 1 : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int h = ht * HT + r * 64 + lane;
+            if (h < a.hn && cnt[r] != 0) atomicAdd(&a.counts[hbase + (long long)h * a.h_h], cnt[r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 4 (v3): winner selection + least-squares refit (P:159-167 and P:176-196).
+// One block per (keypoint, image).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_select_refit(
+    const int *__restrict__ tn_arr, const float2 *__restrict__ coords,
+    const float2 *__restrict__ dirs, const float2 *__restrict__ hyps,
+    const int *__restrict__ counts, double *__restrict__ sums /*[B,K,5]*/,
+    int *__restrict__ singular /*[B,K]*/, float2 *__restrict__ pts /*[B,K]*/,
+    int *__restrict__ win_counts /*[B,K] or null*/, int K, int hn, int cap, float thresh)
+{
+    __shared__ int s_cnt[4], s_idx[4];
+    __shared__ double redd[4];
+    const int vi = blockIdx.x, b = blockIdx.y;
+    const int bk = b * K + vi;
+    const int tn = tn_arr[b];
+    if (tn <= 0) {
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < 5; ++i) sums[(size_t)bk * 5 + i] = 0.0;
+            singular[bk] = 0;
+            pts[bk] = make_float2(0.f, 0.f);
+            if (win_counts) win_counts[bk] = 0;
+        }
+        return;
+    }
+    // torch.max(counts, 0): maximal count, FIRST index among ties (P:160)
+    const int *cp = counts + (size_t)bk * hn;
+    int best = -1, besti = 0x7fffffff;
+    for (int h = threadIdx.x; h < hn; h += kBlock) {
+        int c = cp[h];
+        if (c > best) { best = c; besti = h; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int oc = __shfl_xor(best, o, 64), oi = __shfl_xor(besti, o, 64);
+        if (oc > best || (oc == best && oi < besti)) { best = oc; besti = oi; }
+    }
+    if (lane_id() == 0) { s_cnt[threadIdx.x >> 6] = best; s_idx[threadIdx.x >> 6] = besti; }
+    __syncthreads();
+    best = s_cnt[0]; besti = s_idx[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (s_cnt[w] > best || (s_cnt[w] == best && s_idx[w] < besti)) { best = s_cnt[w]; besti = s_idx[w]; }
+
+    // P:162-167: all_win_ratio (0) < count/tn  <=>  count > 0; otherwise the winner stays (0,0)
+    float2 win = make_float2(0.f, 0.f);
+    if (best > 0) win = hyps[(size_t)bk * hn + besti];
+
+    // P:176-191: re-vote the winner (hn = 1) and accumulate the normal equations in binary64
+    const float2 *dp = dirs + (size_t)bk * cap;
+    const float2 *cq = coords + (size_t)b * cap;
+    double xx = 0, xy = 0, yy = 0, bx = 0, by = 0;
+    for (int ti = threadIdx.x; ti < tn; ti += kBlock) {
+        float2 d = dp[ti], c = cq[ti];
+        if (!vote_exact(c.x, c.y, win.x, win.y, d.x, d.y, thresh)) continue;
+        double nx = (double)d.y, ny = -(double)d.x;          // P:178-179
+        double bb = nx * (double)c.x + ny * (double)c.y;     // P:189
+        xx += nx * nx; xy += nx * ny; yy += ny * ny;         // P:190
+        bx += nx * bb; by += ny * bb;                        // P:191
+    }
+    xx = block_sum(xx, redd); xy = block_sum(xy, redd); yy = block_sum(yy, redd);
+    bx = block_sum(bx, redd); by = block_sum(by, redd);
+    if (threadIdx.x == 0) {
+        double *s = sums + (size_t)bk * 5;
+        s[0] = xx; s[1] = xy; s[2] = yy; s[3] = bx; s[4] = by;
+        double det = xx * yy - xy * xy;
+        bool sing = !(det != 0.0) || !isfinite(det);
+        singular[bk] = sing ? 1 : 0;
+        float2 o = make_float2(0.f, 0.f);
+        if (!sing) {
+            o.x = (float)((yy * bx - xy * by) / det);        // P:193, closed-form 2x2
+            o.y = (float)((xx * by - xy * bx) / det);
+        }
+        pts[bk] = o;
+        if (win_counts) win_counts[bk] = best;
+    }
+}
+
+// Singular-matrix policy across the keypoints of an image (b_inv, P:97-109).
+__global__ void k_finalize_v3(const int *__restrict__ tn_arr, const double *__restrict__ sums,
+                              const int *__restrict__ singular, const float2 *__restrict__ pts,
+                              float2 *__restrict__ out, int B, int K, int policy)
+{
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * K) return;
+    int b = gid / K;
+    float2 o = pts[gid];
+    if (tn_arr[b] > 0 && policy != PVV_SINGULAR_ZERO) {
+        bool any = false;
+        for (int vi = 0; vi < K; ++vi) any |= singular[b * K + vi] != 0;
+        if (any) {
+            if (policy == PVV_SINGULAR_REFERENCE)  // inverse := identity  =>  x = ATb
+                o = make_float2((float)sums[(size_t)gid * 5 + 3], (float)sums[(size_t)gid * 5 + 4]);
+            else                                   // v1: the whole image becomes zeros
+                o = make_float2(0.f, 0.f);
+        }
+    }
+    out[gid] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 4 (estimate): ratio threshold + weighted covariance about `mean` (P:244, P:262-269).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_covariance(
+    const int *__restrict__ tn_arr, const float2 *__restrict__ hyps, const int *__restrict__ counts,
+    const float2 *__restrict__ mean, float *__restrict__ cov /*[B,K,2,2]*/,
+    float2 *__restrict__ hyp_out /*[B,K,hn] or null*/, int *__restrict__ counts_out, int K, int hn)
+{
+    __shared__ int redi[4];
+    __shared__ double redd[4];
+    const int vi = blockIdx.x, b = blockIdx.y;
+    const int bk = b * K + vi;
+    const int tn = tn_arr[b];
+    const float2 m = mean[bk];
+    const float2 *hp = hyps + (size_t)bk * hn;
+    const int *cp = counts + (size_t)bk * hn;
+    if (hyp_out || counts_out)
+        for (int h = threadIdx.x; h < hn; h += kBlock) {
+            if (hyp_out) hyp_out[(size_t)bk * hn + h] = tn > 0 ? hp[h] : make_float2(0.f, 0.f);
+            if (counts_out) counts_out[(size_t)bk * hn + h] = tn > 0 ? cp[h] : 0;
+        }
+    double sxx = 0, sxy = 0, syy = 0, sw = 0;
+    if (tn <= 0) {
+        // P:211-216: hypotheses are zeros, ratios are ones
+        if (threadIdx.x == 0) {
+            double dx = (double)(0.f - m.x), dy = (double)(0.f - m.y);
+            sxx = dx * dx * hn; sxy = dx * dy * hn; syy = dy * dy * hn; sw = (double)hn;
+        }
+    } else {
+        int mx = 0;
+        for (int h = threadIdx.x; h < hn; h += kBlock) mx = max(mx, cp[h]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+        __syncthreads();
+        if (lane_id() == 0) redi[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        mx = max(max(redi[0], redi[1]), max(redi[2], redi[3]));
+        const float ftn = (float)tn;
+        const float thr = (float)mx / ftn - 0.1f;            // P:244, P:262 (binary32)
+        for (int h = threadIdx.x; h < hn; h += kBlock) {
+            float r = (float)cp[h] / ftn;
+            if (r < thr) r = 0.f;                             // P:263
+            float2 q = hp[h];
+            double dx = (double)(q.x - m.x), dy = (double)(q.y - m.y);  // P:266 binary32 diff
+            sxx += (double)r * dx * dx; sxy += (double)r * dx * dy; syy += (double)r * dy * dy;
+            sw += (double)r;
+        }
+    }
+    sxx = block_sum(sxx, redd); sxy = block_sum(sxy, redd);
+    syy = block_sum(syy, redd); sw = block_sum(sw, redd);
+    if (threadIdx.x == 0) {
+        double den = sw + 1e-3;                               // P:269
+        float *c = cov + (size_t)bk * 4;
+        c[0] = (float)(sxx / den); c[1] = (float)(sxy / den);
+        c[2] = (float)(sxy / den); c[3] = (float)(syy / den);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Legacy-layout kernels (module-level drop-in, reference layouts [tn,vn,2] / [hn,vn,*]).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_legacy_gen(const float *__restrict__ direct,
+                                                       const float *__restrict__ coords,
+                                                       const int32_t *__restrict__ idxs,
+                                                       float *__restrict__ hypo, int tn, int vn, int hn)
+{
+    int hvi = blockIdx.x * kBlock + threadIdx.x;
+    if (hvi >= hn * vn) return;
+    int vi = hvi % vn;
+    int t0 = idxs[hvi * 2], t1 = idxs[hvi * 2 + 1];
+    const float2 *d = (const float2 *)direct;
+    const float2 *c = (const float2 *)coords;
+    float2 d0 = d[(size_t)t0 * vn + vi], d1 = d[(size_t)t1 * vn + vi];
+    float2 c0 = c[t0], c1 = c[t1];
+    float2 h = hypothesis_exact(d0.x, d0.y, c0.x, c0.y, d1.x, d1.y, c1.x, c1.y);
+    ((float2 *)hypo)[hvi] = h;
+}
+
+// K:88-126.  Thread = (ti, vi); loops a slab of hypotheses so the pixel is loaded once and the
+// byte stores of a wave are contiguous in ti.
+__global__ __launch_bounds__(kBlock) void k_legacy_vote(const float *__restrict__ direct,
+                                                        const float *__restrict__ coords,
+                                                        const float *__restrict__ hypo,
+                                                        uint8_t *__restrict__ inliers, int tn, int vn,
+                                                        int hn, int h_per_block, float thresh)
+{
+    int ti = blockIdx.x * kBlock + threadIdx.x;
+    int vi = blockIdx.y;
+    int h0 = blockIdx.z * h_per_block;
+    int h1 = min(hn, h0 + h_per_block);
+    if (ti >= tn) return;
+    float2 d = ((const float2 *)direct)[(size_t)ti * vn + vi];
+    float2 c = ((const float2 *)coords)[ti];
+    for (int hi = h0; hi < h1; ++hi) {
+        float2 h = ((const float2 *)hypo)[hi * vn + vi];  // wave-uniform
+        if (vote_exact(c.x, c.y, h.x, h.y, d.x, d.y, thresh))
+            inliers[((size_t)hi * vn + vi) * tn + ti] = 1;
+    }
+}
+
+// K:170-229
+__global__ __launch_bounds__(kBlock) void k_legacy_gen_vp(const float *__restrict__ direct,
+                                                          const float *__restrict__ coords,
+                                                          const int32_t *__restrict__ idxs,
+                                                          float *__restrict__ hypo, int tn, int vn, int hn)
+{
+    int hvi = blockIdx.x * kBlock + threadIdx.x;
+    if (hvi >= hn * vn) return;
+    int vi = hvi % vn;
+    int id0 = idxs[hvi * 2], id1 = idxs[hvi * 2 + 1];
+    const float2 *d = (const float2 *)direct;
+    const float2 *c = (const float2 *)coords;
+    float2 d0 = d[(size_t)id0 * vn + vi], d1 = d[(size_t)id1 * vn + vi];
+    float2 c0 = c[id0], c1 = c[id1];
+    float dx0 = d0.x, dy0 = d0.y, cx0 = c0.x, cy0 = c0.y;
+    float dx1 = d1.x, dy1 = d1.y, cx1 = c1.x, cy1 = c1.y;
+
+    float lx0 = dy0, ly0 = -dx0, lz0 = cy0 * dx0 - cx0 * dy0;
+    float lx1 = dy1, ly1 = -dx1, lz1 = cy1 * dx1 - cx1 * dy1;
+
+    float x = ly0 * lz1 - lz0 * ly1;
+    float y = lz0 * lx1 - lx0 * lz1;
+    float z = lx0 * ly1 - ly0 * lx1;
+
+    float val_x0 = dx0 * (x - z * cx0);
+    float val_x1 = dx1 * (x - z * cx1);
+    float val_y0 = dy0 * (y - z * cy0);
+    float val_y1 = dy1 * (y - z * cy1);
+
+    if (val_x0 < 0 && val_x1 < 0 && val_y0 < 0 && val_y1 < 0) { z = -z; x = -x; y = -y; }
+    if (val_x0 * val_x1 < 0 || val_y0 * val_y1 < 0) { x = 0.f; y = 0.f; z = 0.f; }
+
+    hypo[hvi * 3] = x;
+    hypo[hvi * 3 + 1] = y;
+    hypo[hvi * 3 + 2] = z;
+}
+
+// K:268-310
+__global__ __launch_bounds__(kBlock) void k_legacy_vote_vp(const float *__restrict__ direct,
+                                                           const float *__restrict__ coords,
+                                                           const float *__restrict__ hypo,
+                                                           uint8_t *__restrict__ inliers, int tn, int vn,
+                                                           int hn, int h_per_block, float thresh)
+{
+    int ti = blockIdx.x * kBlock + threadIdx.x;
+    int vi = blockIdx.y;
+    int h0 = blockIdx.z * h_per_block;
+    int h1 = min(hn, h0 + h_per_block);
+    if (ti >= tn) return;
+    float2 d = ((const float2 *)direct)[(size_t)ti * vn + vi];
+    float2 c = ((const float2 *)coords)[ti];
+    float norm1 = sqrtf(d.x * d.x + d.y * d.y);
+    for (int hi = h0; hi < h1; ++hi) {
+        const float *h = hypo + ((size_t)hi * vn + vi) * 3;
+        float hx = h[0], hy = h[1], hz = h[2];
+        float diff_x = hx - c.x * hz;
+        float diff_y = hy - c.y * hz;
+        float norm2 = sqrtf(diff_x * diff_x + diff_y * diff_y);
+        if (lt_1e6(norm1) || lt_1e6(norm2)) continue;
+        float angle_dist = (d.x * diff_x + d.y * diff_y) / (norm1 * norm2);
+        float val_x = diff_x * d.x;
+        float val_y = diff_y * d.y;
+        if (val_x < 0 || val_y < 0) continue;
+        if (fabsf(angle_dist) > thresh) inliers[((size_t)hi * vn + vi) * tn + ti] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Layout {
+    int T;
+    size_t tile_nz, tile_sum, tn, coords, dirs, hyps, counts, sums, singular, pts, total;
+};
+
+Layout make_layout(const pvv_problem *p)
+{
+    Layout L;
+    const size_t HW = (size_t)p->H * p->W;
+    L.T = (int)((HW + kTile - 1) / kTile);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+    L.tile_nz = take(sizeof(int) * (size_t)p->B * L.T);
+    L.tile_sum = take(sizeof(int) * (size_t)p->B * L.T);
+    L.tn = take(sizeof(int) * (size_t)p->B);
+    L.coords = take(sizeof(float2) * (size_t)p->B * p->cap);
+    L.dirs = take(sizeof(float2) * (size_t)p->B * p->K * p->cap);
+    L.hyps = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
+    L.counts = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
+    L.sums = take(sizeof(double) * (size_t)p->B * p->K * 5);
+    L.singular = take(sizeof(int) * (size_t)p->B * p->K);
+    L.pts = take(sizeof(float2) * (size_t)p->B * p->K);
+    L.total = off;
+    return L;
+}
+
+int validate(const pvv_problem *p)
+{
+    if (!p) return fail(PVV_E_ARG, "problem is NULL");
+    if (p->B <= 0 || p->H <= 0 || p->W <= 0 || p->K <= 0 || p->hn <= 0)
+        return fail(PVV_E_ARG, "B, H, W, K, hn must be positive");
+    if (p->B > kMaxBatchLds) return fail(PVV_E_ARG, "B > 1024: split the batch");
+    if ((long long)p->H * p->W >= (1ll << 31)) return fail(PVV_E_ARG, "H*W must be < 2^31");
+    if (p->mask_elem_size != 1 && p->mask_elem_size != 2 && p->mask_elem_size != 4 &&
+        p->mask_elem_size != 8)
+        return fail(PVV_E_ARG, "mask_elem_size must be 1, 2, 4 or 8");
+    if (p->cap <= 0 || (long long)p->cap > (long long)p->H * p->W)
+        return fail(PVV_E_ARG, "cap must be in [1, H*W]");
+    if ((long long)p->B * p->K * p->hn >= (1ll << 31) || (long long)p->B * p->K * p->cap >= (1ll << 40))
+        return fail(PVV_E_ARG, "problem too large for one call");
+    if (p->singular_policy < PVV_SINGULAR_REFERENCE || p->singular_policy > PVV_SINGULAR_IMAGE_ZERO)
+        return fail(PVV_E_ARG, "unknown singular_policy");
+    return PVV_OK;
+}
+
+int num_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+int launch_count(const CountArgs &a, hipStream_t st)
+{
+    const int grid = num_cus() * 8;
+    if (a.hn <= 64)
+        hipLaunchKernelGGL(k_count_inliers<1>, dim3(grid), dim3(kBlock), 0, st, a);
+    else if (a.hn <= 128)
+        hipLaunchKernelGGL(k_count_inliers<2>, dim3(grid), dim3(kBlock), 0, st, a);
+    else if (a.hn <= 256)
+        hipLaunchKernelGGL(k_count_inliers<4>, dim3(grid), dim3(kBlock), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_count_inliers<8>, dim3(grid), dim3(kBlock), 0, st, a);
+    return check_launch("k_count_inliers");
+}
+
+CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
+{
+    CountArgs a;
+    a.coords = (const float2 *)(ws + L.coords);
+    a.dirs = (const float2 *)(ws + L.dirs);
+    a.hyps = (const float2 *)(ws + L.hyps);
+    a.counts = (int *)(ws + L.counts);
+    a.tn_arr = (const int *)(ws + L.tn);
+    a.c_b = p->cap;
+    a.d_b = (long long)p->K * p->cap; a.d_v = p->cap; a.d_p = 1;
+    a.h_b = (long long)p->K * p->hn; a.h_v = p->hn; a.h_h = 1;
+    a.tn_fixed = 0;
+    a.B = p->B; a.K = p->K; a.hn = p->hn;
+    a.thresh = p->inlier_thresh;
+    return a;
+}
+
+template <int ES>
+int launch_compaction(const MaskArgs &m, const VertexArgs &v, const Layout &L, char *ws, int B,
+                      hipStream_t st)
+{
+    dim3 grid(L.T, B), block(kBlock);
+    int *tile_nz = (int *)(ws + L.tile_nz), *tile_sum = (int *)(ws + L.tile_sum);
+    hipLaunchKernelGGL(k_tile_count<ES>, grid, block, 0, st, m, tile_nz, tile_sum);
+    if (int e = check_launch("k_tile_count")) return e;
+    hipLaunchKernelGGL(k_tile_recount<ES>, grid, block, 0, st, m, tile_nz, (const int *)tile_sum);
+    if (int e = check_launch("k_tile_recount")) return e;
+    hipLaunchKernelGGL(k_compact<ES>, grid, block, 0, st, m, v, (const int *)tile_nz,
+                       (const int *)tile_sum, (int *)(ws + L.tn), (float2 *)(ws + L.coords),
+                       (float2 *)(ws + L.dirs));
+    return check_launch("k_compact");
+}
+
+// compaction + hypotheses + counting, shared by both layers
+int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d_vertex,
+              const int32_t *d_idxs, const float *d_selection, char *ws, const Layout &L,
+              hipStream_t st)
+{
+    MaskArgs m;
+    m.mask = d_mask;
+    m.selection = d_selection;
+    m.sb = p->mask_stride[0]; m.sh = p->mask_stride[1]; m.sw = p->mask_stride[2];
+    m.es = p->mask_elem_size;
+    m.contig = (m.sw == 1 && m.sh == p->W) ? 1 : 0;
+    m.mode = mode;
+    m.W = p->W; m.HW = p->H * p->W; m.T = L.T;
+    m.min_num = p->min_num; m.max_num = p->max_num; m.cap = p->cap;
+    m.seed = p->seed;
+    VertexArgs v;
+    v.vertex = d_vertex;
+    v.sb = p->vertex_stride[0]; v.sh = p->vertex_stride[1]; v.sw = p->vertex_stride[2];
+    v.sk = p->vertex_stride[3]; v.sc = p->vertex_stride[4];
+    v.K = p->K;
+    v.vec2 = (v.sc == 1 && !(v.sb & 1) && !(v.sh & 1) && !(v.sw & 1) && !(v.sk & 1) &&
+              ((uintptr_t)d_vertex % 8 == 0)) ? 1 : 0;
+    int e;
+    switch (m.es) {
+    case 1: e = launch_compaction<1>(m, v, L, ws, p->B, st); break;
+    case 2: e = launch_compaction<2>(m, v, L, ws, p->B, st); break;
+    case 4: e = launch_compaction<4>(m, v, L, ws, p->B, st); break;
+    default: e = launch_compaction<8>(m, v, L, ws, p->B, st); break;
+    }
+    if (e) return e;
+
+    const long long nh = (long long)p->B * p->K * p->hn;
+    hipLaunchKernelGGL(k_gen_hypothesis, dim3((unsigned)((nh + kBlock - 1) / kBlock)), dim3(kBlock),
+                       0, st, d_idxs, (const int *)(ws + L.tn), (const float2 *)(ws + L.coords),
+                       (const float2 *)(ws + L.dirs), (float2 *)(ws + L.hyps), (int *)(ws + L.counts),
+                       p->B, p->K, p->hn, p->cap, p->seed);
+    if ((e = check_launch("k_gen_hypothesis"))) return e;
+    return launch_count(planar_count_args(p, L, ws), st);
+}
+
+int check_ptrs(const pvv_problem *p, const void *mask, const void *vertex, void *ws, size_t ws_bytes,
+               Layout *L)
+{
+    if (int e = validate(p)) return e;
+    if (!mask || !vertex || !ws) return fail(PVV_E_ARG, "mask, vertex and workspace must be non-NULL");
+    *L = make_layout(p);
+    if (ws_bytes < L->total) return fail(PVV_E_WORKSPACE, "workspace too small");
+    return PVV_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+PVV_EXPORT int pvv_abi_version(void) { return PVV_ABI_VERSION; }
+PVV_EXPORT const char *pvv_last_error(void) { return g_err; }
+
+PVV_EXPORT int32_t pvv_default_cap(int32_t H, int32_t W, int32_t max_num)
+{
+    long long hw = (long long)H * W;
+    if (max_num < 0) max_num = 0;
+    long long cap = (long long)max_num + (long long)(8.0 * std::sqrt((double)max_num)) + 64;
+    return (int32_t)(cap < hw ? cap : hw);
+}
+
+PVV_EXPORT size_t pvv_workspace_bytes(const pvv_problem *p)
+{
+    if (validate(p)) return 0;
+    return make_layout(p).total;
+}
+
+PVV_EXPORT int pvv_ransac_voting_v3(const pvv_problem *p, const void *d_mask, const float *d_vertex,
+                                    const int32_t *d_idxs, const float *d_selection,
+                                    void *d_workspace, size_t workspace_bytes, float *d_out,
+                                    int32_t *d_win_counts, int32_t *d_tn, void *stream)
+{
+    Layout L;
+    if (int e = check_ptrs(p, d_mask, d_vertex, d_workspace, workspace_bytes, &L)) return e;
+    if (!d_out) return fail(PVV_E_ARG, "d_out is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)d_workspace;
+    if (int e = run_front(p, 0, d_mask, d_vertex, d_idxs, d_selection, ws, L, st)) return e;
+
+    hipLaunchKernelGGL(k_select_refit, dim3(p->K, p->B), dim3(kBlock), 0, st,
+                       (const int *)(ws + L.tn), (const float2 *)(ws + L.coords),
+                       (const float2 *)(ws + L.dirs), (const float2 *)(ws + L.hyps),
+                       (const int *)(ws + L.counts), (double *)(ws + L.sums),
+                       (int *)(ws + L.singular), (float2 *)(ws + L.pts), d_win_counts, p->K, p->hn,
+                       p->cap, p->inlier_thresh);
+    if (int e = check_launch("k_select_refit")) return e;
+    const int n = p->B * p->K;
+    hipLaunchKernelGGL(k_finalize_v3, dim3((n + 255) / 256), dim3(256), 0, st,
+                       (const int *)(ws + L.tn), (const double *)(ws + L.sums),
+                       (const int *)(ws + L.singular), (const float2 *)(ws + L.pts),
+                       (float2 *)d_out, p->B, p->K, p->singular_policy);
+    if (int e = check_launch("k_finalize_v3")) return e;
+    if (d_tn) {
+        hipError_t e = hipMemcpyAsync(d_tn, ws + L.tn, sizeof(int) * p->B, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+    return PVV_OK;
+}
+
+PVV_EXPORT int pvv_estimate_voting_distribution(const pvv_problem *p, const void *d_mask,
+                                                const float *d_vertex, const int32_t *d_idxs,
+                                                const float *d_selection, const float *d_mean,
+                                                void *d_workspace, size_t workspace_bytes,
+                                                float *d_cov, float *d_hyp, int32_t *d_counts,
+                                                int32_t *d_tn, void *stream)
+{
+    Layout L;
+    if (int e = check_ptrs(p, d_mask, d_vertex, d_workspace, workspace_bytes, &L)) return e;
+    if (!d_mean || !d_cov) return fail(PVV_E_ARG, "d_mean / d_cov is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)d_workspace;
+    if (int e = run_front(p, 1, d_mask, d_vertex, d_idxs, d_selection, ws, L, st)) return e;
+    hipLaunchKernelGGL(k_covariance, dim3(p->K, p->B), dim3(kBlock), 0, st,
+                       (const int *)(ws + L.tn), (const float2 *)(ws + L.hyps),
+                       (const int *)(ws + L.counts), (const float2 *)d_mean, d_cov, (float2 *)d_hyp,
+                       d_counts, p->K, p->hn);
+    if (int e = check_launch("k_covariance")) return e;
+    if (d_tn) {
+        hipError_t e = hipMemcpyAsync(d_tn, ws + L.tn, sizeof(int) * p->B, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+    return PVV_OK;
+}
+
+PVV_EXPORT int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace, size_t workspace_bytes,
+                                      void *stream)
+{
+    if (int e = validate(p)) return e;
+    if (!d_workspace) return fail(PVV_E_ARG, "workspace is NULL");
+    Layout L = make_layout(p);
+    if (workspace_bytes < L.total) return fail(PVV_E_WORKSPACE, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)d_workspace;
+    hipError_t e = hipMemsetAsync(ws + L.counts, 0, sizeof(int) * (size_t)p->B * p->K * p->hn, st);
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return launch_count(planar_count_args(p, L, ws), st);
+}
+
+// ---- legacy module surface ---------------------------------------------------------------
+static int check_legacy(const void *a, const void *b, const void *c, const void *d, int tn, int vn,
+                        int hn)
+{
+    if (!a || !b || !c || !d) return fail(PVV_E_ARG, "NULL device pointer");
+    if (tn < 0 || vn <= 0 || hn < 0) return fail(PVV_E_ARG, "tn, hn must be >= 0 and vn > 0");
+    if ((long long)hn * vn * (long long)(tn > 0 ? tn : 1) >= (1ll << 40))
+        return fail(PVV_E_ARG, "problem too large");
+    return PVV_OK;
+}
+
+PVV_EXPORT int pvv_generate_hypothesis(const float *d_direct, const float *d_coords,
+                                       const int32_t *d_idxs, float *d_hypo_pts, int tn, int vn,
+                                       int hn, void *stream)
+{
+    if (int e = check_legacy(d_direct, d_coords, d_idxs, d_hypo_pts, tn, vn, hn)) return e;
+    if (hn == 0) return PVV_OK;
+    hipLaunchKernelGGL(k_legacy_gen, dim3((hn * vn + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       (hipStream_t)stream, d_direct, d_coords, d_idxs, d_hypo_pts, tn, vn, hn);
+    return check_launch("k_legacy_gen");
+}
+
+PVV_EXPORT int pvv_generate_hypothesis_vanishing_point(const float *d_direct, const float *d_coords,
+                                                       const int32_t *d_idxs, float *d_hypo_pts,
+                                                       int tn, int vn, int hn, void *stream)
+{
+    if (int e = check_legacy(d_direct, d_coords, d_idxs, d_hypo_pts, tn, vn, hn)) return e;
+    if (hn == 0) return PVV_OK;
+    hipLaunchKernelGGL(k_legacy_gen_vp, dim3((hn * vn + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       (hipStream_t)stream, d_direct, d_coords, d_idxs, d_hypo_pts, tn, vn, hn);
+    return check_launch("k_legacy_gen_vp");
+}
+
+static void legacy_vote_shape(int tn, int vn, int hn, dim3 *grid, int *h_per_block)
+{
+    // enough blocks to fill 256 CUs, few enough that each thread amortises its pixel load
+    int tiles = (tn + kBlock - 1) / kBlock;
+    int hz = 1;
+    while ((long long)tiles * vn * hz < 4096 && hz < hn) hz <<= 1;
+    if (hz > hn) hz = hn;
+    if (hz > 65535) hz = 65535;
+    *h_per_block = (hn + hz - 1) / hz;
+    *grid = dim3(tiles, vn, (hn + *h_per_block - 1) / *h_per_block);
+}
+
+PVV_EXPORT int pvv_voting_for_hypothesis(const float *d_direct, const float *d_coords,
+                                         const float *d_hypo_pts, uint8_t *d_inliers, int tn, int vn,
+                                         int hn, float inlier_thresh, void *stream)
+{
+    if (int e = check_legacy(d_direct, d_coords, d_hypo_pts, d_inliers, tn, vn, hn)) return e;
+    if (vn > 65535) return fail(PVV_E_ARG, "vn > 65535");
+    if (hn == 0 || tn == 0) return PVV_OK;
+    dim3 grid; int hpb;
+    legacy_vote_shape(tn, vn, hn, &grid, &hpb);
+    hipLaunchKernelGGL(k_legacy_vote, grid, dim3(kBlock), 0, (hipStream_t)stream, d_direct, d_coords,
+                       d_hypo_pts, d_inliers, tn, vn, hn, hpb, inlier_thresh);
+    return check_launch("k_legacy_vote");
+}
+
+PVV_EXPORT int pvv_voting_for_hypothesis_vanishing_point(const float *d_direct, const float *d_coords,
+                                                         const float *d_hypo_pts, uint8_t *d_inliers,
+                                                         int tn, int vn, int hn, float inlier_thresh,
+                                                         void *stream)
+{
+    if (int e = check_legacy(d_direct, d_coords, d_hypo_pts, d_inliers, tn, vn, hn)) return e;
+    if (vn > 65535) return fail(PVV_E_ARG, "vn > 65535");
+    if (hn == 0 || tn == 0) return PVV_OK;
+    dim3 grid; int hpb;
+    legacy_vote_shape(tn, vn, hn, &grid, &hpb);
+    hipLaunchKernelGGL(k_legacy_vote_vp, grid, dim3(kBlock), 0, (hipStream_t)stream, d_direct,
+                       d_coords, d_hypo_pts, d_inliers, tn, vn, hn, hpb, inlier_thresh);
+    return check_launch("k_legacy_vote_vp");
+}
+
+PVV_EXPORT int pvv_count_inliers(const float *d_direct, const float *d_coords, const float *d_hypo_pts,
+                                 int32_t *d_counts, int tn, int vn, int hn, float inlier_thresh,
+                                 void *stream)
+{
+    if (int e = check_legacy(d_direct, d_coords, d_hypo_pts, d_counts, tn, vn, hn)) return e;
+    if (hn == 0) return PVV_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t me = hipMemsetAsync(d_counts, 0, sizeof(int) * (size_t)hn * vn, st);
+    if (me != hipSuccess) return fail((int)me, hipGetErrorString(me));
+    if (tn == 0) return PVV_OK;
+    CountArgs a;
+    a.coords = (const float2 *)d_coords;
+    a.dirs = (const float2 *)d_direct;
+    a.hyps = (const float2 *)d_hypo_pts;
+    a.counts = d_counts;
+    a.tn_arr = nullptr;
+    a.c_b = 0;
+    a.d_b = 0; a.d_v = 1; a.d_p = vn;      // direct[ti,vi]
+    a.h_b = 0; a.h_v = 1; a.h_h = vn;      // hypo[hi,vi], counts[hi,vi]
+    a.tn_fixed = tn;
+    a.B = 1; a.K = vn; a.hn = hn;
+    a.thresh = inlier_thresh;
+    return launch_count(a, st);
+}

@@ -1,0 +1,310 @@
+// ransac_voting_ext.cpp -- pybind11/torch shim over the C ABI of libpvnet_vote.so.
+//
+// Reproduces the extension-module surface of the reference
+// (/root/reference/lib/csrc/ransac_voting/src/ransac_voting.cpp:102-107): the module is called
+// `ransac_voting` and exports generate_hypothesis, voting_for_hypothesis,
+// generate_hypothesis_vanishing_point and voting_for_hypothesis_vanishing_point with the
+// reference's argument order and ownership rules (generate_* allocate and return a tensor,
+// voting_* mutate `inliers` in place).  Differences, all deliberate:
+//   * launches go to the CURRENT torch HIP stream, not the legacy default stream
+//     (ransac_voting_kernel.cu:76,159 use <<<bdim,tdim>>>);
+//   * device / dtype / contiguity / every dimension are checked with TORCH_CHECK
+//     (-> Python RuntimeError) where the reference has CHECK_INPUT (ransac_voting.cpp:7-9) plus
+//     bare assert()s (kernel.cu:61-65) and exit() on a launch error (cuda_common.h:19-26).
+// This file contains no device code; it is compiled by the host compiler only.
+#include <c10/hip/HIPStream.h>
+#include <torch/extension.h>
+
+#include <optional>
+#include <tuple>
+
+#include "pvnet_vote.h"
+
+namespace {
+
+void *cur_stream(const at::Tensor &t)
+{
+    return (void *)c10::hip::getCurrentHIPStream(t.device().index()).stream();
+}
+
+void check_dev(const at::Tensor &t, const char *name, at::ScalarType st)
+{
+    TORCH_CHECK(t.is_cuda(), name, " must be a CUDA tensor");  // message as ransac_voting.cpp:7
+    TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");  // ransac_voting.cpp:8
+    TORCH_CHECK(t.scalar_type() == st, name, " must have dtype ", st, ", got ", t.scalar_type());
+}
+
+void same_device(const at::Tensor &a, const at::Tensor &b, const char *nb)
+{
+    TORCH_CHECK(a.device() == b.device(), nb, " is on ", b.device(), ", expected ", a.device());
+}
+
+void ok(int code, const char *what)
+{
+    TORCH_CHECK(code == 0, what, " failed (", code, "): ", pvv_last_error());
+}
+
+struct Dims { int tn, vn, hn; };
+
+Dims check_gen(const at::Tensor &direct, const at::Tensor &coords, const at::Tensor &idxs)
+{
+    check_dev(direct, "direct", at::kFloat);
+    check_dev(coords, "coords", at::kFloat);
+    check_dev(idxs, "idxs", at::kInt);
+    same_device(direct, coords, "coords");
+    same_device(direct, idxs, "idxs");
+    TORCH_CHECK(direct.dim() == 3 && direct.size(2) == 2, "direct must be [tn,vn,2]");
+    const int64_t tn = direct.size(0), vn = direct.size(1);
+    TORCH_CHECK(vn > 0, "direct must have vn > 0");
+    TORCH_CHECK(coords.dim() == 2 && coords.size(0) == tn && coords.size(1) == 2, "coords must be [tn,2]");
+    TORCH_CHECK(idxs.dim() == 3 && idxs.size(1) == vn && idxs.size(2) == 2, "idxs must be [hn,vn,2]");
+    TORCH_CHECK(tn > 0 || idxs.size(0) == 0, "idxs index an empty pixel list");
+    return {(int)tn, (int)vn, (int)idxs.size(0)};
+}
+
+Dims check_vote(const at::Tensor &direct, const at::Tensor &coords, const at::Tensor &hypo_pts,
+                const at::Tensor &inliers, int hdim)
+{
+    check_dev(direct, "direct", at::kFloat);
+    check_dev(coords, "coords", at::kFloat);
+    check_dev(hypo_pts, "hypo_pts", at::kFloat);
+    check_dev(inliers, "inliers", at::kByte);
+    same_device(direct, coords, "coords");
+    same_device(direct, hypo_pts, "hypo_pts");
+    same_device(direct, inliers, "inliers");
+    TORCH_CHECK(direct.dim() == 3 && direct.size(2) == 2, "direct must be [tn,vn,2]");
+    const int64_t tn = direct.size(0), vn = direct.size(1);
+    TORCH_CHECK(vn > 0, "direct must have vn > 0");
+    TORCH_CHECK(coords.dim() == 2 && coords.size(0) == tn && coords.size(1) == 2, "coords must be [tn,2]");
+    TORCH_CHECK(hypo_pts.dim() == 3 && hypo_pts.size(1) == vn && hypo_pts.size(2) == hdim,
+                "hypo_pts must be [hn,vn,", hdim, "]");
+    const int64_t hn = hypo_pts.size(0);
+    TORCH_CHECK(inliers.dim() == 3 && inliers.size(0) == hn && inliers.size(1) == vn && inliers.size(2) == tn,
+                "inliers must be [hn,vn,tn]");
+    return {(int)tn, (int)vn, (int)hn};
+}
+
+// ---- reference module surface -----------------------------------------------------------
+
+at::Tensor generate_hypothesis(at::Tensor direct, at::Tensor coords, at::Tensor idxs)
+{
+    Dims d = check_gen(direct, coords, idxs);
+    auto hypo_pts = at::empty({d.hn, d.vn, 2}, direct.options());
+    ok(pvv_generate_hypothesis(direct.data_ptr<float>(), coords.data_ptr<float>(), idxs.data_ptr<int32_t>(),
+                               hypo_pts.data_ptr<float>(), d.tn, d.vn, d.hn, cur_stream(direct)),
+       "generate_hypothesis");
+    return hypo_pts;
+}
+
+void voting_for_hypothesis(at::Tensor direct, at::Tensor coords, at::Tensor hypo_pts, at::Tensor inliers,
+                           float inlier_thresh)
+{
+    Dims d = check_vote(direct, coords, hypo_pts, inliers, 2);
+    ok(pvv_voting_for_hypothesis(direct.data_ptr<float>(), coords.data_ptr<float>(), hypo_pts.data_ptr<float>(),
+                                 inliers.data_ptr<uint8_t>(), d.tn, d.vn, d.hn, inlier_thresh,
+                                 cur_stream(direct)),
+       "voting_for_hypothesis");
+}
+
+at::Tensor generate_hypothesis_vanishing_point(at::Tensor direct, at::Tensor coords, at::Tensor idxs)
+{
+    Dims d = check_gen(direct, coords, idxs);
+    auto hypo_pts = at::empty({d.hn, d.vn, 3}, direct.options());
+    ok(pvv_generate_hypothesis_vanishing_point(direct.data_ptr<float>(), coords.data_ptr<float>(),
+                                               idxs.data_ptr<int32_t>(), hypo_pts.data_ptr<float>(), d.tn,
+                                               d.vn, d.hn, cur_stream(direct)),
+       "generate_hypothesis_vanishing_point");
+    return hypo_pts;
+}
+
+void voting_for_hypothesis_vanishing_point(at::Tensor direct, at::Tensor coords, at::Tensor hypo_pts,
+                                           at::Tensor inliers, float inlier_thresh)
+{
+    Dims d = check_vote(direct, coords, hypo_pts, inliers, 3);
+    ok(pvv_voting_for_hypothesis_vanishing_point(direct.data_ptr<float>(), coords.data_ptr<float>(),
+                                                 hypo_pts.data_ptr<float>(), inliers.data_ptr<uint8_t>(),
+                                                 d.tn, d.vn, d.hn, inlier_thresh, cur_stream(direct)),
+       "voting_for_hypothesis_vanishing_point");
+}
+
+// ---- additions -----------------------------------------------------------------------------
+
+// voting_for_hypothesis + sum over tn without the [hn,vn,tn] scratch -> [hn,vn] int32
+at::Tensor count_inliers(at::Tensor direct, at::Tensor coords, at::Tensor hypo_pts, float inlier_thresh)
+{
+    check_dev(direct, "direct", at::kFloat);
+    check_dev(coords, "coords", at::kFloat);
+    check_dev(hypo_pts, "hypo_pts", at::kFloat);
+    same_device(direct, coords, "coords");
+    same_device(direct, hypo_pts, "hypo_pts");
+    TORCH_CHECK(direct.dim() == 3 && direct.size(2) == 2, "direct must be [tn,vn,2]");
+    const int64_t tn = direct.size(0), vn = direct.size(1);
+    TORCH_CHECK(vn > 0, "direct must have vn > 0");
+    TORCH_CHECK(coords.dim() == 2 && coords.size(0) == tn && coords.size(1) == 2, "coords must be [tn,2]");
+    TORCH_CHECK(hypo_pts.dim() == 3 && hypo_pts.size(1) == vn && hypo_pts.size(2) == 2, "hypo_pts must be [hn,vn,2]");
+    auto counts = at::empty({hypo_pts.size(0), vn}, direct.options().dtype(at::kInt));
+    ok(pvv_count_inliers(direct.data_ptr<float>(), coords.data_ptr<float>(), hypo_pts.data_ptr<float>(),
+                         counts.data_ptr<int32_t>(), (int)tn, (int)vn, (int)hypo_pts.size(0), inlier_thresh,
+                         cur_stream(direct)),
+       "count_inliers");
+    return counts;
+}
+
+int mask_elem_size(const at::Tensor &mask)
+{
+    switch (mask.scalar_type()) {
+    case at::kBool: case at::kByte: case at::kChar: return 1;
+    case at::kShort: return 2;
+    case at::kInt: return 4;
+    case at::kLong: return 8;
+    default: TORCH_CHECK(false, "mask must be a bool or integer tensor, got ", mask.scalar_type());
+    }
+}
+
+pvv_problem make_problem(const at::Tensor &mask, const at::Tensor &vertex, int64_t hn, double thresh,
+                         int64_t min_num, int64_t max_num, int64_t policy, int64_t seed)
+{
+    TORCH_CHECK(mask.is_cuda(), "mask must be a CUDA tensor");
+    TORCH_CHECK(vertex.is_cuda(), "vertex must be a CUDA tensor");
+    same_device(mask, vertex, "vertex");
+    TORCH_CHECK(vertex.scalar_type() == at::kFloat, "vertex must be float32, got ", vertex.scalar_type());
+    TORCH_CHECK(vertex.dim() == 5 && vertex.size(4) == 2, "vertex must be [b,h,w,vn,2]");
+    TORCH_CHECK(mask.dim() == 3 && mask.size(0) == vertex.size(0) && mask.size(1) == vertex.size(1) &&
+                    mask.size(2) == vertex.size(2),
+                "mask must be [b,h,w] matching vertex");
+    TORCH_CHECK(hn > 0 && hn < (1 << 24), "hypothesis count must be in [1, 2^24)");
+    TORCH_CHECK(vertex.size(0) > 0 && vertex.size(3) > 0, "empty batch / no keypoints");
+    pvv_problem p;
+    memset(&p, 0, sizeof(p));
+    p.B = (int32_t)vertex.size(0); p.H = (int32_t)vertex.size(1); p.W = (int32_t)vertex.size(2);
+    p.K = (int32_t)vertex.size(3);
+    p.hn = (int32_t)hn;
+    p.mask_elem_size = mask_elem_size(mask);
+    const int64_t big = std::numeric_limits<int32_t>::max();
+    p.min_num = (int32_t)std::max<int64_t>(-big, std::min<int64_t>(big, min_num));
+    p.max_num = (int32_t)std::max<int64_t>(0, std::min<int64_t>(big, max_num));
+    p.cap = pvv_default_cap(p.H, p.W, p.max_num);
+    p.singular_policy = (int32_t)policy;
+    p.inlier_thresh = (float)thresh;
+    for (int i = 0; i < 3; ++i) p.mask_stride[i] = mask.stride(i);
+    for (int i = 0; i < 5; ++i) p.vertex_stride[i] = vertex.stride(i);
+    p.seed = (uint64_t)seed;
+    return p;
+}
+
+const int32_t *opt_idxs(const std::optional<at::Tensor> &idxs, const at::Tensor &vertex, const pvv_problem &p)
+{
+    if (!idxs.has_value()) return nullptr;
+    const at::Tensor &t = *idxs;
+    check_dev(t, "idxs", at::kInt);
+    same_device(vertex, t, "idxs");
+    TORCH_CHECK(t.dim() == 4 && t.size(0) == p.B && t.size(1) == p.hn && t.size(2) == p.K && t.size(3) == 2,
+                "idxs must be [b,hn,vn,2] = [", p.B, ",", p.hn, ",", p.K, ",2]");
+    return t.data_ptr<int32_t>();
+}
+
+const float *opt_selection(const std::optional<at::Tensor> &sel, const at::Tensor &vertex, const pvv_problem &p)
+{
+    if (!sel.has_value()) return nullptr;
+    const at::Tensor &t = *sel;
+    check_dev(t, "selection", at::kFloat);
+    same_device(vertex, t, "selection");
+    TORCH_CHECK(t.dim() == 3 && t.size(0) == p.B && t.size(1) == p.H && t.size(2) == p.W,
+                "selection must be [b,h,w]");
+    return t.data_ptr<float>();
+}
+
+at::Tensor make_workspace(const pvv_problem &p, const at::Tensor &like)
+{
+    size_t n = pvv_workspace_bytes(&p);
+    TORCH_CHECK(n > 0, "invalid voting problem: ", pvv_last_error());
+    return at::empty({(int64_t)n}, like.options().dtype(at::kByte));
+}
+
+// ransac_voting_layer_v3 for the whole batch -> (kpt [b,vn,2], win_counts [b,vn], tn [b], workspace)
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> ransac_voting_v3(
+    at::Tensor mask, at::Tensor vertex, int64_t round_hyp_num, double inlier_thresh, int64_t min_num,
+    int64_t max_num, std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection, int64_t seed,
+    int64_t singular_policy)
+{
+    pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num,
+                                 singular_policy, seed);
+    const int32_t *ip = opt_idxs(idxs, vertex, p);
+    const float *sp = opt_selection(selection, vertex, p);
+    at::Tensor ws = make_workspace(p, vertex);
+    auto out = at::empty({p.B, p.K, 2}, vertex.options());
+    auto win = at::empty({p.B, p.K}, vertex.options().dtype(at::kInt));
+    auto tn = at::empty({p.B}, vertex.options().dtype(at::kInt));
+    ok(pvv_ransac_voting_v3(&p, mask.data_ptr(), vertex.data_ptr<float>(), ip, sp, ws.data_ptr(),
+                            (size_t)ws.numel(), out.data_ptr<float>(), win.data_ptr<int32_t>(),
+                            tn.data_ptr<int32_t>(), cur_stream(vertex)),
+       "ransac_voting_v3");
+    return {out, win, tn, ws};
+}
+
+// estimate_voting_distribution_with_mean for the whole batch
+// -> (cov [b,vn,2,2], hyp [b,vn,hn,2] | empty, counts [b,vn,hn] | empty, tn [b])
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> estimate_voting_distribution(
+    at::Tensor mask, at::Tensor vertex, at::Tensor mean, int64_t hyp_total, double inlier_thresh,
+    int64_t min_num, int64_t max_num, std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection,
+    int64_t seed, bool want_hyp)
+{
+    pvv_problem p = make_problem(mask, vertex, hyp_total, inlier_thresh, min_num, max_num, 0, seed);
+    check_dev(mean, "mean", at::kFloat);
+    same_device(vertex, mean, "mean");
+    TORCH_CHECK(mean.dim() == 3 && mean.size(0) == p.B && mean.size(1) == p.K && mean.size(2) == 2,
+                "mean must be [b,vn,2]");
+    const int32_t *ip = opt_idxs(idxs, vertex, p);
+    const float *sp = opt_selection(selection, vertex, p);
+    at::Tensor ws = make_workspace(p, vertex);
+    auto cov = at::empty({p.B, p.K, 2, 2}, vertex.options());
+    auto tn = at::empty({p.B}, vertex.options().dtype(at::kInt));
+    at::Tensor hyp, counts;
+    if (want_hyp) {
+        hyp = at::empty({p.B, p.K, p.hn, 2}, vertex.options());
+        counts = at::empty({p.B, p.K, p.hn}, vertex.options().dtype(at::kInt));
+    } else {
+        hyp = at::empty({0}, vertex.options());
+        counts = at::empty({0}, vertex.options().dtype(at::kInt));
+    }
+    ok(pvv_estimate_voting_distribution(&p, mask.data_ptr(), vertex.data_ptr<float>(), ip, sp,
+                                        mean.data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(),
+                                        cov.data_ptr<float>(), want_hyp ? hyp.data_ptr<float>() : nullptr,
+                                        want_hyp ? counts.data_ptr<int32_t>() : nullptr,
+                                        tn.data_ptr<int32_t>(), cur_stream(vertex)),
+       "estimate_voting_distribution");
+    return {cov, hyp, counts, tn};
+}
+
+// Re-run only the inlier-count kernel on the state a previous ransac_voting_v3 call left in `ws`
+// (bench.py brackets this with HIP events to get the dominant kernel's duration).
+void rerun_count_kernel(at::Tensor mask, at::Tensor vertex, int64_t hn, double inlier_thresh, int64_t min_num,
+                        int64_t max_num, at::Tensor ws)
+{
+    pvv_problem p = make_problem(mask, vertex, hn, inlier_thresh, min_num, max_num, 0, 0);
+    check_dev(ws, "workspace", at::kByte);
+    ok(pvv_rerun_count_kernel(&p, ws.data_ptr(), (size_t)ws.numel(), cur_stream(vertex)), "rerun_count_kernel");
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    // the reference's four (ransac_voting.cpp:102-107), same names and docstrings' meaning
+    m.def("generate_hypothesis", &generate_hypothesis, "generate hypothesis");
+    m.def("voting_for_hypothesis", &voting_for_hypothesis, "voting for hypothesis");
+    m.def("generate_hypothesis_vanishing_point", &generate_hypothesis_vanishing_point,
+          "generate hypothesis vanishing point");
+    m.def("voting_for_hypothesis_vanishing_point", &voting_for_hypothesis_vanishing_point,
+          "voting for hypothesis vanishing point");
+    // fused / batched additions
+    m.def("count_inliers", &count_inliers, "fused vote + count -> [hn,vn] int32");
+    m.def("ransac_voting_v3", &ransac_voting_v3, "batched ransac_voting_layer_v3");
+    m.def("estimate_voting_distribution", &estimate_voting_distribution,
+          "batched estimate_voting_distribution_with_mean");
+    m.def("rerun_count_kernel", &rerun_count_kernel, "re-launch the inlier-count kernel (profiling aid)");
+    m.attr("abi_version") = pvv_abi_version();
+    m.attr("SINGULAR_REFERENCE") = (int)PVV_SINGULAR_REFERENCE;
+    m.attr("SINGULAR_ZERO") = (int)PVV_SINGULAR_ZERO;
+    m.attr("SINGULAR_IMAGE_ZERO") = (int)PVV_SINGULAR_IMAGE_ZERO;
+}

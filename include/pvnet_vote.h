@@ -1,0 +1,163 @@
+/*
+ * pvnet_vote.h -- C ABI of libpvnet_vote.so: clean-pvnet's RANSAC voting hot
+ * path as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * Every pointer named d_* is a DEVICE pointer (HBM) owned by the caller; the
+ * library allocates nothing, synchronises nothing and launches everything on
+ * the `stream` it is given (a hipStream_t passed as void*; NULL = the null
+ * stream).  All entry points return 0 on success and a non-zero code on
+ * failure (PVV_E_*; > 0 values are hipError_t from a failed launch);
+ * pvv_last_error() returns a thread-local human readable message.  There is
+ * no CPU fallback anywhere in this library.
+ *
+ * Citations are into /root/reference (zju3dv/clean-pvnet):
+ *   K = lib/csrc/ransac_voting/src/ransac_voting_kernel.cu
+ *   C = lib/csrc/ransac_voting/src/ransac_voting.cpp
+ *   P = lib/csrc/ransac_voting/ransac_voting_gpu.py
+ */
+#ifndef PVNET_VOTE_H_
+#define PVNET_VOTE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVV_OK 0
+#define PVV_E_ARG (-1)       /* bad shape / size / NULL pointer              */
+#define PVV_E_WORKSPACE (-2) /* workspace smaller than pvv_workspace_bytes() */
+
+/* ABI version of this header; pvv_abi_version() must return the same. */
+#define PVV_ABI_VERSION 1
+
+int pvv_abi_version(void);
+const char *pvv_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Legacy extension-module surface: the four functions the reference's
+ * pybind module `ransac_voting` exports (C:102-107).  Layouts exactly as the
+ * reference: direct [tn,vn,2] f32, coords [tn,2] f32 (x,y), idxs [hn,vn,2]
+ * i32, hypo_pts [hn,vn,2|3] f32, inliers [hn,vn,tn] u8 -- all contiguous.
+ * ---------------------------------------------------------------------- */
+
+/* Replaces generate_hypothesis (C:20-31 -> K:51-86 -> kernel K:11-49).
+ * d_hypo_pts is fully written: (0,0) for degenerate pairs, as at::zeros + the
+ * kernel's early return give in the reference (K:42-43,75). */
+int pvv_generate_hypothesis(const float *d_direct, const float *d_coords,
+                            const int32_t *d_idxs, float *d_hypo_pts, int tn,
+                            int vn, int hn, void *stream);
+
+/* Replaces voting_for_hypothesis (C:41-55 -> K:129-167 -> kernel K:88-126).
+ * In/out d_inliers: only ever written with 1; the caller pre-zeroes (P:155). */
+int pvv_voting_for_hypothesis(const float *d_direct, const float *d_coords,
+                              const float *d_hypo_pts, uint8_t *d_inliers,
+                              int tn, int vn, int hn, float inlier_thresh,
+                              void *stream);
+
+/* Replaces generate_hypothesis_vanishing_point (C:64-75 -> K:231-266 -> K:170-229). */
+int pvv_generate_hypothesis_vanishing_point(const float *d_direct,
+                                            const float *d_coords,
+                                            const int32_t *d_idxs,
+                                            float *d_hypo_pts, int tn, int vn,
+                                            int hn, void *stream);
+
+/* Replaces voting_for_hypothesis_vanishing_point (C:85-99 -> K:313-351 -> K:268-310). */
+int pvv_voting_for_hypothesis_vanishing_point(const float *d_direct,
+                                              const float *d_coords,
+                                              const float *d_hypo_pts,
+                                              uint8_t *d_inliers, int tn,
+                                              int vn, int hn,
+                                              float inlier_thresh,
+                                              void *stream);
+
+/* Fused voting_for_hypothesis + torch.sum(inlier, 2) (P:155-159) on the
+ * reference layouts: d_counts [hn,vn] i32, fully written.  No [hn,vn,tn]
+ * scratch exists. */
+int pvv_count_inliers(const float *d_direct, const float *d_coords,
+                      const float *d_hypo_pts, int32_t *d_counts, int tn,
+                      int vn, int hn, float inlier_thresh, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Batched, sync-free voting layers (replace the per-image Python loops of
+ * P:112-199 and P:202-274).  One call = the whole batch, no host read-back.
+ * ---------------------------------------------------------------------- */
+
+typedef struct pvv_problem {
+    int32_t B, H, W, K;      /* images, rows, cols, keypoints (vn)            */
+    int32_t hn;              /* hypotheses per keypoint evaluated in this call */
+    int32_t mask_elem_size;  /* bytes per mask element: 1,2,4,8 (bool/intN)   */
+    int32_t min_num;         /* P:129 / P:211                                  */
+    int32_t max_num;         /* P:135 / P:219                                  */
+    int32_t cap;             /* rows reserved per image for compacted pixels;
+                                use pvv_default_cap()                          */
+    int32_t singular_policy; /* PVV_SINGULAR_*; v3 only                        */
+    float inlier_thresh;     /* P:112 / P:202                                  */
+    int64_t mask_stride[3];  /* element strides of mask   [B,H,W]              */
+    int64_t vertex_stride[5];/* element strides of vertex [B,H,W,K,2] (any view,
+                                e.g. the planar permute of resnet18.py:66-68)  */
+    uint64_t seed;           /* counter-based RNG key, used when d_idxs /
+                                d_selection are NULL                           */
+} pvv_problem;
+
+/* b_inv (P:97-109) falls back to the identity for the WHOLE image when the
+ * batched solve raises; REFERENCE reproduces that (x = ATb for every keypoint
+ * of an image that has a singular keypoint), ZERO confines the damage to the
+ * singular keypoint, which becomes (0,0). */
+#define PVV_SINGULAR_REFERENCE 0
+#define PVV_SINGULAR_ZERO 1
+/* ransac_voting_layer (v1, P:86-91): torch.inverse raises for the whole image
+ * -> every keypoint of that image becomes (0,0). */
+#define PVV_SINGULAR_IMAGE_ZERO 2
+
+/* Rows to reserve per image: H*W when max_num >= H*W, otherwise max_num plus
+ * 8 sigma of the binomial subsample of P:135-138 (a longer list is truncated). */
+int32_t pvv_default_cap(int32_t H, int32_t W, int32_t max_num);
+
+/* Bytes of device scratch the two layer calls below need for `p`. */
+size_t pvv_workspace_bytes(const pvv_problem *p);
+
+/* ransac_voting_layer_v3 (P:112-199).
+ *   d_mask      [B,H,W] integer/bool mask, foreground = low byte != 0 (P:125)
+ *   d_vertex    [B,H,W,K,2] f32 through p->vertex_stride
+ *   d_idxs      [B,hn,K,2] i32 injected index pairs of P:145, or NULL (device RNG)
+ *   d_selection [B,H,W] f32 injected U(0,1) draws of P:136, or NULL (device RNG)
+ *   d_out       [B,K,2] f32 keypoint means
+ *   d_win_counts[B,K] i32 inlier count of each winner (optional, may be NULL)
+ *   d_tn        [B] i32 foreground pixels used per image (optional)
+ * The confidence loop of P:150-174 cannot change the result (idxs are drawn
+ * once, P:145) and is not executed. */
+int pvv_ransac_voting_v3(const pvv_problem *p, const void *d_mask,
+                         const float *d_vertex, const int32_t *d_idxs,
+                         const float *d_selection, void *d_workspace,
+                         size_t workspace_bytes, float *d_out,
+                         int32_t *d_win_counts, int32_t *d_tn, void *stream);
+
+/* estimate_voting_distribution_with_mean (P:202-274); p->hn is the TOTAL
+ * number of hypotheses (round_num * round_hyp_num, P:231-249).
+ *   d_mask      foreground = element == 1 (P:207)
+ *   d_idxs      [B,hn,K,2] i32 (the rounds of P:235 concatenated) or NULL
+ *   d_mean      [B,K,2] f32
+ *   d_cov       [B,K,2,2] f32
+ *   d_hyp       [B,K,hn,2] f32 all hypotheses (optional, may be NULL)
+ *   d_counts    [B,K,hn] i32 their inlier counts (optional) */
+int pvv_estimate_voting_distribution(const pvv_problem *p, const void *d_mask,
+                                     const float *d_vertex,
+                                     const int32_t *d_idxs,
+                                     const float *d_selection,
+                                     const float *d_mean, void *d_workspace,
+                                     size_t workspace_bytes, float *d_cov,
+                                     float *d_hyp, int32_t *d_counts,
+                                     int32_t *d_tn, void *stream);
+
+/* Bench / profiling aid: re-runs ONLY the inlier-count kernel of the last
+ * layer call recorded in `d_workspace` (same problem), so its duration can be
+ * bracketed with HIP events on `stream`. */
+int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace,
+                           size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVNET_VOTE_H_ */

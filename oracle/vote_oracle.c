@@ -1,0 +1,332 @@
+/*
+ * vote_oracle.c -- CPU restatement of clean-pvnet's RANSAC voting path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the timed CPU baseline.
+ *
+ * PARITY STATUS: "parity unpinned" by the reference's own tests -- the
+ * reference ships no tests, golden vectors or CPU implementation for this
+ * path, and its CUDA sources cannot be built here.
+ * The kernels below restate the .cu sources line by line; the Python glue
+ * restated in vote_oracle.py is additionally pinned against the reference's
+ * own ransac_voting_gpu.py executed on CPU (tests/golden/make_golden.py).
+ *
+ * Arithmetic contract: IEEE-754 binary32, one rounding per source-level
+ * operation, left to right as written in the reference, NO fused
+ * multiply-add (build with -ffp-contract=off, never -ffast-math).  This is
+ * the definition of "bit-exact inlier counts" for the whole repository.
+ *
+ * Reference files restated here (paths relative to /root/reference):
+ *   lib/csrc/ransac_voting/src/ransac_voting_kernel.cu:11-49    generate_hypothesis_kernel
+ *   lib/csrc/ransac_voting/src/ransac_voting_kernel.cu:88-126   voting_for_hypothesis_kernel
+ *   lib/csrc/ransac_voting/src/ransac_voting_kernel.cu:170-229  generate_hypothesis_vanishing_point_kernel
+ *   lib/csrc/ransac_voting/src/ransac_voting_kernel.cu:268-310  voting_for_hypothesis_vanishing_point_kernel
+ *   lib/csrc/ransac_voting/ransac_voting_gpu.py:150-196         select + refit of ransac_voting_layer_v3
+ *   lib/csrc/ransac_voting/ransac_voting_gpu.py:231-269         rounds + covariance of estimate_voting_distribution_with_mean
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ */
+/* kernel.cu:22-48 -- one (hi,vi) of generate_hypothesis_kernel.       */
+/* Returns 0 when the pair is degenerate (output left untouched).      */
+static inline int hyp_one(const float *direct, const float *coords, int vn,
+                          int vi, int t0, int t1, float *x_out, float *y_out)
+{
+    float nx0 = direct[t0 * vn * 2 + vi * 2 + 1];
+    float ny0 = -direct[t0 * vn * 2 + vi * 2];
+    float cx0 = coords[t0 * 2];
+    float cy0 = coords[t0 * 2 + 1];
+
+    float nx1 = direct[t1 * vn * 2 + vi * 2 + 1];
+    float ny1 = -direct[t1 * vn * 2 + vi * 2];
+    float cx1 = coords[t1 * 2];
+    float cy1 = coords[t1 * 2 + 1];
+
+    /* kernel.cu:42-43: fabs(float) compared against the double literal 1e-6 */
+    float den_y = nx1 * ny0 - nx0 * ny1;
+    float den_x = ny1 * nx0 - ny0 * nx1;
+    if ((double)fabsf(den_y) < 1e-6) return 0;
+    if ((double)fabsf(den_x) < 1e-6) return 0;
+    /* kernel.cu:44-45 */
+    float y = (nx1 * (nx0 * cx0 + ny0 * cy0) - nx0 * (nx1 * cx1 + ny1 * cy1)) / den_y;
+    float x = (ny1 * (nx0 * cx0 + ny0 * cy0) - ny0 * (nx1 * cx1 + ny1 * cy1)) / den_x;
+    *x_out = x;
+    *y_out = y;
+    return 1;
+}
+
+/* kernel.cu:51-86 -- launcher semantics: output is zero-filled (at::zeros, :75). */
+ORC_API void orc_generate_hypothesis(const float *direct, const float *coords,
+                                     const int32_t *idxs, float *hypo_pts,
+                                     int tn, int vn, int hn)
+{
+    (void)tn;
+    memset(hypo_pts, 0, sizeof(float) * (size_t)hn * vn * 2);
+    for (int hi = 0; hi < hn; ++hi)
+        for (int vi = 0; vi < vn; ++vi) {
+            int t0 = idxs[hi * vn * 2 + vi * 2];
+            int t1 = idxs[hi * vn * 2 + vi * 2 + 1];
+            float x, y;
+            if (hyp_one(direct, coords, vn, vi, t0, t1, &x, &y)) {
+                hypo_pts[hi * vn * 2 + vi * 2] = x;
+                hypo_pts[hi * vn * 2 + vi * 2 + 1] = y;
+            }
+        }
+}
+
+/* kernel.cu:100-125 -- the decision of one (hi,vi,ti) thread. */
+static inline int vote_one(float cx, float cy, float hx, float hy, float nx,
+                           float ny, float thresh)
+{
+    float dx = hx - cx;
+    float dy = hy - cy;
+    float norm1 = sqrtf(nx * nx + ny * ny);
+    float norm2 = sqrtf(dx * dx + dy * dy);
+    if ((double)norm1 < 1e-6 || (double)norm2 < 1e-6) return 0;
+    float angle_dist = (dx * nx + dy * ny) / (norm1 * norm2);
+    return angle_dist > thresh;
+}
+
+/* kernel.cu:88-126 -- writes 1 only; the caller pre-zeroes `inliers`. */
+ORC_API void orc_voting_for_hypothesis(const float *direct, const float *coords,
+                                       const float *hypo_pts, uint8_t *inliers,
+                                       int tn, int vn, int hn, float thresh)
+{
+    for (int hi = 0; hi < hn; ++hi)
+        for (int vi = 0; vi < vn; ++vi) {
+            float hx = hypo_pts[hi * vn * 2 + vi * 2];
+            float hy = hypo_pts[hi * vn * 2 + vi * 2 + 1];
+            uint8_t *row = inliers + ((size_t)hi * vn + vi) * tn;
+            for (int ti = 0; ti < tn; ++ti)
+                if (vote_one(coords[ti * 2], coords[ti * 2 + 1], hx, hy,
+                             direct[ti * vn * 2 + vi * 2],
+                             direct[ti * vn * 2 + vi * 2 + 1], thresh))
+                    row[ti] = 1;
+        }
+}
+
+/* voting_for_hypothesis + torch.sum(inlier, 2) (ransac_voting_gpu.py:156-159)
+ * without materialising the [hn,vn,tn] scratch.  counts is [hn,vn] int32.
+ * This is also the function timed as bench.py's cpu_baseline ("port"). */
+ORC_API void orc_count_inliers(const float *direct, const float *coords,
+                               const float *hypo_pts, int32_t *counts, int tn,
+                               int vn, int hn, float thresh)
+{
+#pragma omp parallel for schedule(static)
+    for (int hv = 0; hv < hn * vn; ++hv) {
+        int vi = hv % vn;
+        float hx = hypo_pts[hv * 2];
+        float hy = hypo_pts[hv * 2 + 1];
+        int32_t c = 0;
+        for (int ti = 0; ti < tn; ++ti)
+            c += vote_one(coords[ti * 2], coords[ti * 2 + 1], hx, hy,
+                          direct[ti * vn * 2 + vi * 2],
+                          direct[ti * vn * 2 + vi * 2 + 1], thresh);
+        counts[hv] = c;
+    }
+}
+
+/* kernel.cu:170-229 */
+ORC_API void orc_generate_hypothesis_vanishing_point(const float *direct,
+                                                     const float *coords,
+                                                     const int32_t *idxs,
+                                                     float *hypo_pts, int tn,
+                                                     int vn, int hn)
+{
+    (void)tn;
+    for (int hi = 0; hi < hn; ++hi)
+        for (int vi = 0; vi < vn; ++vi) {
+            int id0 = idxs[hi * vn * 2 + vi * 2];
+            int id1 = idxs[hi * vn * 2 + vi * 2 + 1];
+            float dx0 = direct[id0 * vn * 2 + vi * 2];
+            float dy0 = direct[id0 * vn * 2 + vi * 2 + 1];
+            float cx0 = coords[id0 * 2];
+            float cy0 = coords[id0 * 2 + 1];
+            float dx1 = direct[id1 * vn * 2 + vi * 2];
+            float dy1 = direct[id1 * vn * 2 + vi * 2 + 1];
+            float cx1 = coords[id1 * 2];
+            float cy1 = coords[id1 * 2 + 1];
+
+            float lx0 = dy0, ly0 = -dx0, lz0 = cy0 * dx0 - cx0 * dy0;
+            float lx1 = dy1, ly1 = -dx1, lz1 = cy1 * dx1 - cx1 * dy1;
+
+            float x = ly0 * lz1 - lz0 * ly1;
+            float y = lz0 * lx1 - lx0 * lz1;
+            float z = lx0 * ly1 - ly0 * lx1;
+
+            float val_x0 = dx0 * (x - z * cx0);
+            float val_x1 = dx1 * (x - z * cx1);
+            float val_y0 = dy0 * (y - z * cy0);
+            float val_y1 = dy1 * (y - z * cy1);
+
+            if (val_x0 < 0 && val_x1 < 0 && val_y0 < 0 && val_y1 < 0) {
+                z = -z; x = -x; y = -y;
+            }
+            if (val_x0 * val_x1 < 0 || val_y0 * val_y1 < 0) {
+                x = 0.f; y = 0.f; z = 0.f;
+            }
+            hypo_pts[hi * vn * 3 + vi * 3] = x;
+            hypo_pts[hi * vn * 3 + vi * 3 + 1] = y;
+            hypo_pts[hi * vn * 3 + vi * 3 + 2] = z;
+        }
+}
+
+/* kernel.cu:268-310 */
+ORC_API void orc_voting_for_hypothesis_vanishing_point(
+    const float *direct, const float *coords, const float *hypo_pts,
+    uint8_t *inliers, int tn, int vn, int hn, float thresh)
+{
+    for (int hi = 0; hi < hn; ++hi)
+        for (int vi = 0; vi < vn; ++vi) {
+            float hx = hypo_pts[hi * vn * 3 + vi * 3];
+            float hy = hypo_pts[hi * vn * 3 + vi * 3 + 1];
+            float hz = hypo_pts[hi * vn * 3 + vi * 3 + 2];
+            uint8_t *row = inliers + ((size_t)hi * vn + vi) * tn;
+            for (int ti = 0; ti < tn; ++ti) {
+                float cx = coords[ti * 2], cy = coords[ti * 2 + 1];
+                float direct_x = direct[ti * vn * 2 + vi * 2];
+                float direct_y = direct[ti * vn * 2 + vi * 2 + 1];
+                float diff_x = hx - cx * hz;
+                float diff_y = hy - cy * hz;
+                float norm1 = sqrtf(direct_x * direct_x + direct_y * direct_y);
+                float norm2 = sqrtf(diff_x * diff_x + diff_y * diff_y);
+                if ((double)norm1 < 1e-6 || (double)norm2 < 1e-6) continue;
+                float angle_dist = (direct_x * diff_x + direct_y * diff_y) / (norm1 * norm2);
+                float val_x = diff_x * direct_x;
+                float val_y = diff_y * direct_y;
+                if (val_x < 0 || val_y < 0) continue;
+                if (fabsf(angle_dist) > thresh) row[ti] = 1;
+            }
+        }
+}
+
+/* ------------------------------------------------------------------ */
+/* ransac_voting_gpu.py:150-196 for ONE image whose foreground has     */
+/* already been compacted to direct[tn,vn,2] / coords[tn,2].           */
+/*                                                                    */
+/* idxs [hn,vn,2] is drawn once before the confidence loop (:145), so */
+/* iterations 2..n recompute identical values and `larger_mask` is    */
+/* all-false: the output equals the state after iteration 1           */
+/* (SURVEY.md appendix A.3).  The loop is therefore not restated.     */
+/*                                                                    */
+/* Normal equations are accumulated in binary64 and rounded once;     */
+/* the reference accumulates in binary32 (torch.matmul/sum), which is */
+/* what the 1e-4 tolerance of the parity tests absorbs.               */
+/*                                                                    */
+/* Outputs: win_pts [vn,2] (the RANSAC winners before the refit),     */
+/* win_counts [vn], win_idx [vn], ATA [vn,3] = (xx,xy,yy), ATb [vn,2], */
+/* singular [vn] (det == 0 or non-finite in binary64).                */
+ORC_API void orc_v3_image(const float *direct, const float *coords,
+                          const int32_t *idxs, int tn, int vn, int hn,
+                          float thresh, float *hypo_pts /* [hn,vn,2] scratch */,
+                          int32_t *counts /* [hn,vn] scratch */,
+                          float *win_pts, int32_t *win_counts, int32_t *win_idx,
+                          double *ATA, double *ATb, int32_t *singular,
+                          float *out_pts /* [vn,2] per-keypoint solve */)
+{
+    orc_generate_hypothesis(direct, coords, idxs, hypo_pts, tn, vn, hn);
+    orc_count_inliers(direct, coords, hypo_pts, counts, tn, vn, hn, thresh);
+
+    for (int vi = 0; vi < vn; ++vi) {
+        /* torch.max(counts, 0): first maximal index (:160) */
+        int32_t best = -1, best_i = 0;
+        for (int hi = 0; hi < hn; ++hi)
+            if (counts[hi * vn + vi] > best) { best = counts[hi * vn + vi]; best_i = hi; }
+        win_counts[vi] = best;
+        win_idx[vi] = best_i;
+        /* :162-167  all_win_ratio(=0) < count/tn  <=>  count > 0 */
+        float ratio = (float)best / (float)tn;
+        if (0.0f < ratio) {
+            win_pts[vi * 2] = hypo_pts[best_i * vn * 2 + vi * 2];
+            win_pts[vi * 2 + 1] = hypo_pts[best_i * vn * 2 + vi * 2 + 1];
+        } else {
+            win_pts[vi * 2] = 0.f;
+            win_pts[vi * 2 + 1] = 0.f;
+        }
+    }
+
+    /* :176-191 re-vote the winners (hn=1) and build the normal equations */
+    for (int vi = 0; vi < vn; ++vi) {
+        double xx = 0, xy = 0, yy = 0, bx = 0, by = 0;
+        float hx = win_pts[vi * 2], hy = win_pts[vi * 2 + 1];
+        for (int ti = 0; ti < tn; ++ti) {
+            float dxv = direct[ti * vn * 2 + vi * 2];
+            float dyv = direct[ti * vn * 2 + vi * 2 + 1];
+            float cx = coords[ti * 2], cy = coords[ti * 2 + 1];
+            if (!vote_one(cx, cy, hx, hy, dxv, dyv, thresh)) continue;
+            double nx = (double)dyv, ny = -(double)dxv; /* :178-179 */
+            double b = nx * (double)cx + ny * (double)cy; /* :189 */
+            xx += nx * nx; xy += nx * ny; yy += ny * ny;  /* :190 */
+            bx += nx * b;  by += ny * b;                  /* :191 */
+        }
+        ATA[vi * 3] = xx; ATA[vi * 3 + 1] = xy; ATA[vi * 3 + 2] = yy;
+        ATb[vi * 2] = bx; ATb[vi * 2 + 1] = by;
+        /* :193 x = ATA^-1 ATb, closed form 2x2 in binary64 */
+        double det = xx * yy - xy * xy;
+        int sing = !(det != 0.0) || !isfinite(det);
+        singular[vi] = sing;
+        if (sing) {
+            out_pts[vi * 2] = 0.f; out_pts[vi * 2 + 1] = 0.f;
+        } else {
+            out_pts[vi * 2] = (float)((yy * bx - xy * by) / det);
+            out_pts[vi * 2 + 1] = (float)((xx * by - xy * bx) / det);
+        }
+    }
+}
+
+/* ransac_voting_gpu.py:231-269 for ONE compacted image.               */
+/* idxs [hn_total,vn,2] holds the `round_num` rounds concatenated      */
+/* (:235,249), `foreground` is tn as float (:244).                     */
+/* Outputs: hypo_pts [hn_total,vn,2], counts [hn_total,vn],            */
+/* cov [vn,2,2] (binary64 accumulation, rounded once).                 */
+ORC_API void orc_estimate_image(const float *direct, const float *coords,
+                                const int32_t *idxs, int tn, int vn,
+                                int hn_total, float thresh, const float *mean,
+                                float *hypo_pts, int32_t *counts, float *cov)
+{
+    orc_generate_hypothesis(direct, coords, idxs, hypo_pts, tn, vn, hn_total);
+    orc_count_inliers(direct, coords, hypo_pts, counts, tn, vn, hn_total, thresh);
+    for (int vi = 0; vi < vn; ++vi) {
+        /* :244 ratio = count.float()/foreground.float(); :262 max - 0.1 (binary32) */
+        float mx = -INFINITY;
+        for (int hi = 0; hi < hn_total; ++hi) {
+            float r = (float)counts[hi * vn + vi] / (float)tn;
+            if (r > mx) mx = r;
+        }
+        float thr = mx - 0.1f;
+        double sxx = 0, sxy = 0, syy = 0, sw = 0;
+        for (int hi = 0; hi < hn_total; ++hi) {
+            float r = (float)counts[hi * vn + vi] / (float)tn;
+            if (r < thr) r = 0.0f; /* :263 */
+            double dx = (double)(hypo_pts[hi * vn * 2 + vi * 2] - mean[vi * 2]);      /* :266 binary32 diff */
+            double dy = (double)(hypo_pts[hi * vn * 2 + vi * 2 + 1] - mean[vi * 2 + 1]);
+            sxx += (double)r * dx * dx; sxy += (double)r * dx * dy; syy += (double)r * dy * dy;
+            sw += (double)r;
+        }
+        /* :269 cov /= sum(ratio) + 1e-3 */
+        double den = sw + 1e-3;
+        cov[vi * 4] = (float)(sxx / den);
+        cov[vi * 4 + 1] = (float)(sxy / den);
+        cov[vi * 4 + 2] = (float)(sxy / den);
+        cov[vi * 4 + 3] = (float)(syy / den);
+    }
+}
+
+ORC_API int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,405 @@
+"""GPU parity tests: the HIP path against the CPU oracle on identical seeded inputs.
+
+Contract (BASELINE.json north_star): inlier counts / masks / indices bit-exact; keypoint means and
+covariances within 1e-4 (absolute for means -- pixel units; absolute + relative for covariances).
+Every layer is exercised both through the pybind11 module (what clean-pvnet imports) and through the
+raw C ABI of include/pvnet_vote.h (tests/capi.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import capi
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-4
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _compacted(oracle, synth, cfg, seed=1234, **over):
+    d = synth.make_batch(**{**synth.CONFIGS[cfg], **over, "B": 1}, seed=seed)
+    fg, coords, direct = oracle.compact_v3(_np(d["mask"][0]), _np(d["vertex"][0]))
+    return coords, direct
+
+
+def _rand_idxs(tn, hn, vn, seed):
+    rng = np.random.RandomState(seed)
+    return rng.randint(0, tn, size=(hn, vn, 2)).astype(np.int32)
+
+
+# --------------------------------------------------------------------------------------------------
+# extension-module surface (reference layouts)
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,hn", [("cfg1", 64), ("cfg2", 512), ("cfg1", 37)])
+def test_generate_hypothesis_bit_exact(oracle, synth, pkg, gpu, cfg, hn):
+    from clean_pvnet_amd import ransac_voting as ext
+    coords, direct = _compacted(oracle, synth, cfg)
+    tn, vn, _ = direct.shape
+    idxs = _rand_idxs(tn, hn, vn, 1)
+    idxs[0, :, 1] = idxs[0, :, 0]                       # t0 == t1 -> degenerate -> (0,0)
+    want = oracle.generate_hypothesis(direct, coords, idxs)
+    got = ext.generate_hypothesis(torch.from_numpy(direct).to(gpu), torch.from_numpy(coords).to(gpu),
+                                  torch.from_numpy(idxs).to(gpu))
+    assert got.shape == (hn, vn, 2) and got.dtype == torch.float32
+    np.testing.assert_array_equal(_np(got).view(np.uint32), want.view(np.uint32))
+    assert (want[0] == 0).all()
+
+
+@pytest.mark.parametrize("cfg,hn,thresh", [("cfg1", 64, 0.99), ("cfg2", 96, 0.99), ("cfg1", 5, 0.999)])
+def test_voting_for_hypothesis_bit_exact(oracle, synth, pkg, gpu, cfg, hn, thresh):
+    from clean_pvnet_amd import ransac_voting as ext
+    coords, direct = _compacted(oracle, synth, cfg)
+    tn, vn, _ = direct.shape
+    hyp = oracle.generate_hypothesis(direct, coords, _rand_idxs(tn, hn, vn, 2))
+    want = oracle.voting_for_hypothesis(direct, coords, hyp, np.zeros((hn, vn, tn), np.uint8), thresh)
+    inl = torch.zeros(hn, vn, tn, dtype=torch.uint8, device=gpu)
+    ret = ext.voting_for_hypothesis(torch.from_numpy(direct).to(gpu), torch.from_numpy(coords).to(gpu),
+                                    torch.from_numpy(hyp).to(gpu), inl, thresh)
+    assert ret is None                                   # in place, like the reference
+    np.testing.assert_array_equal(_np(inl), want)
+    assert want.sum() > 0
+    # "only writes 1": pre-set bytes survive (ransac_voting_kernel.cu:124-125 never stores 0)
+    inl2 = torch.full((hn, vn, tn), 7, dtype=torch.uint8, device=gpu)
+    ext.voting_for_hypothesis(torch.from_numpy(direct).to(gpu), torch.from_numpy(coords).to(gpu),
+                              torch.from_numpy(hyp).to(gpu), inl2, thresh)
+    np.testing.assert_array_equal(_np(inl2), np.where(want == 1, 1, 7))
+
+
+def test_vanishing_point_pair_bit_exact(oracle, synth, pkg, gpu):
+    from clean_pvnet_amd import ransac_voting as ext
+    coords, direct = _compacted(oracle, synth, "cfg1")
+    tn, vn, _ = direct.shape
+    hn = 48
+    idxs = _rand_idxs(tn, hn, vn, 3)
+    want_h = oracle.generate_hypothesis_vanishing_point(direct, coords, idxs)
+    d, c = torch.from_numpy(direct).to(gpu), torch.from_numpy(coords).to(gpu)
+    got_h = ext.generate_hypothesis_vanishing_point(d, c, torch.from_numpy(idxs).to(gpu))
+    assert got_h.shape == (hn, vn, 3)
+    np.testing.assert_array_equal(_np(got_h).view(np.uint32), want_h.view(np.uint32))
+    want = oracle.voting_for_hypothesis_vanishing_point(direct, coords, want_h, np.zeros((hn, vn, tn), np.uint8), 0.99)
+    inl = torch.zeros(hn, vn, tn, dtype=torch.uint8, device=gpu)
+    ext.voting_for_hypothesis_vanishing_point(d, c, got_h, inl, 0.99)
+    np.testing.assert_array_equal(_np(inl), want)
+    assert want.sum() > 0
+
+
+@pytest.mark.parametrize("cfg,hn,thresh", [("cfg1", 64, 0.99), ("cfg2", 512, 0.99), ("cfg2", 100, 0.999),
+                                           ("cfg1", 1, 0.99), ("cfg1", 700, 0.99)])
+def test_count_inliers_bit_exact(oracle, synth, pkg, gpu, cfg, hn, thresh):
+    """The hot kernel on reference layouts: counts equal the oracle's, and equal
+    voting_for_hypothesis + sum (ransac_voting_gpu.py:156-159) computed on the GPU."""
+    from clean_pvnet_amd import ransac_voting as ext
+    coords, direct = _compacted(oracle, synth, cfg)
+    tn, vn, _ = direct.shape
+    hyp = oracle.generate_hypothesis(direct, coords, _rand_idxs(tn, hn, vn, 4))
+    want = oracle.count_inliers(direct, coords, hyp, thresh)
+    d, c, h = (torch.from_numpy(x).to(gpu) for x in (direct, coords, hyp))
+    got = ext.count_inliers(d, c, h, thresh)
+    assert got.dtype == torch.int32 and got.shape == (hn, vn)
+    np.testing.assert_array_equal(_np(got), want)
+    inl = torch.zeros(hn, vn, tn, dtype=torch.uint8, device=gpu)
+    ext.voting_for_hypothesis(d, c, h, inl, thresh)
+    np.testing.assert_array_equal(_np(inl.sum(2, dtype=torch.int32)), want)
+    assert want.max() > 0
+
+
+def test_count_inliers_adversarial_near_threshold(oracle, pkg, gpu):
+    """Pixels whose cosine to the hypothesis sits within a few ulps of the threshold, plus the
+    norm < 1e-6 guards, zero directions, NaN/Inf -- decisions must still be bit-exact."""
+    from clean_pvnet_amd import ransac_voting as ext
+    rng = np.random.RandomState(7)
+    tn, vn, hn = 4096, 3, 128
+    thresh = 0.99
+    coords = np.stack([rng.randint(0, 640, tn), rng.randint(0, 480, tn)], 1).astype(np.float32)
+    hyp = (rng.rand(hn, vn, 2) * [640, 480]).astype(np.float32)
+    hyp[0] = coords[0]                                   # hypothesis exactly on a pixel: norm2 = 0
+    hyp[1] = coords[1] + np.float32(5e-7)                # norm2 below the 1e-6 guard
+    direct = np.empty((tn, vn, 2), np.float32)
+    ang0 = np.arccos(thresh)
+    for ti in range(tn):
+        h = hyp[rng.randint(hn), :, :]                   # aim each pixel at some hypothesis ...
+        d = h - coords[ti]
+        base = np.arctan2(d[:, 1], d[:, 0])
+        off = ang0 * (1 + rng.uniform(-3e-6, 3e-6, vn)) * rng.choice([-1, 1], vn)   # ... at ~acos(thresh)
+        scale = rng.choice([1.0, 1e-3, 37.5, 1e-7], vn, p=[0.7, 0.1, 0.15, 0.05])
+        direct[ti, :, 0] = np.cos(base + off) * scale
+        direct[ti, :, 1] = np.sin(base + off) * scale
+    direct[5] = 0.0
+    direct[6, 0] = [np.nan, 1.0]
+    direct[7, 1] = [np.inf, 1.0]
+    direct[8] = 1e-7
+    want = oracle.count_inliers(direct, coords, hyp, thresh)
+    got = ext.count_inliers(torch.from_numpy(direct).to(gpu), torch.from_numpy(coords).to(gpu),
+                            torch.from_numpy(hyp).to(gpu), thresh)
+    np.testing.assert_array_equal(_np(got), want)
+    assert 0 < want.sum() < tn * vn * hn
+    # and through the raw C ABI
+    L = capi.load()
+    d, c, h = (torch.from_numpy(x).to(gpu) for x in (direct, coords, hyp))
+    cnt = torch.empty(hn, vn, dtype=torch.int32, device=gpu)
+    capi.check(L.pvv_count_inliers(capi.ptr(d), capi.ptr(c), capi.ptr(h), capi.ptr(cnt), tn, vn, hn, thresh,
+                                   capi.stream()))
+    np.testing.assert_array_equal(_np(cnt), want)
+
+
+def test_extension_rejects_bad_inputs(pkg, gpu):
+    from clean_pvnet_amd import ransac_voting as ext
+    d = torch.zeros(10, 3, 2, device=gpu)
+    c = torch.zeros(10, 2, device=gpu)
+    i = torch.zeros(4, 3, 2, dtype=torch.int32, device=gpu)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        ext.generate_hypothesis(d.cpu(), c, i)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ext.generate_hypothesis(d.transpose(0, 1).contiguous().transpose(0, 1), c, i)
+    with pytest.raises(RuntimeError, match="dtype"):
+        ext.generate_hypothesis(d, c, i.long())
+    with pytest.raises(RuntimeError, match="idxs must be"):
+        ext.generate_hypothesis(d, c, i[:, :2].contiguous())
+    with pytest.raises(RuntimeError, match="inliers must be"):
+        ext.voting_for_hypothesis(d, c, torch.zeros(4, 3, 2, device=gpu),
+                                  torch.zeros(4, 3, 9, dtype=torch.uint8, device=gpu), 0.99)
+
+
+# --------------------------------------------------------------------------------------------------
+# ransac_voting_layer_v3
+# --------------------------------------------------------------------------------------------------
+def _v3_case(oracle, synth, gpu, cfg, B, planar=False, mask_dtype=torch.int64, hn=None, thresh=0.99,
+             max_num=30000, seed=1234, **over):
+    c = {**synth.CONFIGS[cfg], **over, "B": B}
+    hn = hn or c["hn"]
+    d = synth.make_batch(**c, seed=seed, mask_dtype=mask_dtype, planar=planar)
+    mask, vertex = d["mask"], d["vertex"]
+    tn = [int(x) for x in (mask != 0).sum((1, 2))]
+    idxs = synth.make_idxs(tn, hn, c["K"], seed=seed)
+    return d, mask, vertex, idxs, hn, tn
+
+
+def _check_v3(oracle, got_out, got_win, got_tn, mask, vertex, idxs, hn, thresh, singular="reference", selection=None,
+              max_num=30000):
+    details = []
+    want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, thresh, idxs=_np(idxs), details=details,
+                                         singular=singular, selection=None if selection is None else _np(selection),
+                                         max_num=max_num)
+    want_tn = np.array([r["tn"] for r in details], np.int32)
+    want_win = np.stack([r["win_counts"] if not r["skipped"] else np.zeros(vertex.shape[3], np.int32)
+                         for r in details])
+    np.testing.assert_array_equal(_np(got_tn), want_tn)
+    np.testing.assert_array_equal(_np(got_win), want_win)          # inlier counts: bit-exact
+    np.testing.assert_allclose(_np(got_out), want, rtol=0, atol=ATOL)
+    return want, details
+
+
+@pytest.mark.parametrize("cfg,B,planar,mask_dtype", [
+    ("cfg1", 1, False, torch.int64),
+    ("cfg1", 3, True, torch.uint8),
+    ("cfg2", 1, False, torch.int64),
+    ("cfg2", 2, True, torch.int64),
+    ("cfg2", 2, False, torch.bool),
+    ("cfg1", 2, False, torch.int32),
+    ("cfg1", 2, False, torch.int16),
+])
+def test_v3_parity_pybind_and_cabi(oracle, synth, pkg, gpu, cfg, B, planar, mask_dtype):
+    from clean_pvnet_amd import ransac_voting as ext
+    d, mask, vertex, idxs, hn, tn = _v3_case(oracle, synth, gpu, cfg, B, planar, mask_dtype)
+    m, v, i = mask.to(gpu), vertex.to(gpu), idxs.to(gpu)
+    if planar:
+        store = vertex.permute(0, 3, 4, 1, 2).reshape(B, -1, *vertex.shape[1:3]).contiguous().to(gpu)   # [B,2K,H,W]
+        v = store.permute(0, 2, 3, 1).view(*vertex.shape)
+        assert not v.is_contiguous()
+    mm = m.view(torch.uint8) if m.dtype == torch.bool else m
+    out, win, tnn, _ws = ext.ransac_voting_v3(mm, v, hn, 0.99, 5, 30000, i, None, 0, ext.SINGULAR_REFERENCE)
+    want, _ = _check_v3(oracle, out, win, tnn, mask, vertex, idxs, hn, 0.99)
+    # voting recovers the keypoints the field was built from (compute_vertex known answer)
+    assert np.abs(want - _np(d["kpt_2d"])).max() < 2.0
+    out2, win2, tn2 = capi.v3(mm, v, hn, 0.99, idxs=i)
+    np.testing.assert_array_equal(_np(out2), _np(out))
+    np.testing.assert_array_equal(_np(win2), _np(win))
+
+
+def test_v3_python_layer_matches_reference_signature_use(oracle, synth, pkg, gpu):
+    """The three call forms of resnet18.py:71-75 through the drop-in import path."""
+    from lib.csrc.ransac_voting.ransac_voting_gpu import (estimate_voting_distribution_with_mean,
+                                                          ransac_voting_layer_v3)
+    d, mask, vertex, idxs, hn, tn = _v3_case(oracle, synth, gpu, "cfg2", 2)
+    m, v = mask.to(gpu), vertex.to(gpu)
+    mean = ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.99, idxs=idxs.to(gpu))
+    assert mean.shape == (2, 9, 2) and mean.dtype == torch.float32 and mean.is_cuda
+    _check_v3(oracle, mean, *_aux(oracle, mask, vertex, idxs, hn, gpu), mask, vertex, idxs, hn, 0.99)
+    # free-running RNG forms: statistical parity = known-answer recovery
+    torch.manual_seed(0)
+    mean_r = ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.99)
+    assert np.abs(_np(mean_r) - _np(d["kpt_2d"])).max() < 2.0
+    torch.manual_seed(0)
+    np.testing.assert_array_equal(_np(ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.99)), _np(mean_r))
+    mean2, var = estimate_voting_distribution_with_mean(m, v, mean_r)
+    assert mean2 is mean_r and var.shape == (2, 9, 2, 2)
+    assert torch.isfinite(var).all() and (var[:, :, 0, 0] > 0).all() and (var[:, :, 1, 1] > 0).all()
+    kp = ransac_voting_layer_v3(m, v, 128, inlier_thresh=0.99, max_num=100)       # resnet18.py:75
+    assert np.abs(_np(kp) - _np(d["kpt_2d"])).max() < 6.0
+
+
+def _aux(oracle, mask, vertex, idxs, hn, gpu):
+    """win_counts / tn of the product for a v3 problem (through the pybind module)."""
+    from clean_pvnet_amd import ransac_voting as ext
+    _o, win, tn, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), hn, 0.99, 5, 30000, idxs.to(gpu), None, 0,
+                                            ext.SINGULAR_REFERENCE)
+    return win, tn
+
+
+def test_v3_empty_tiny_and_multiclass_images(oracle, synth, pkg, gpu):
+    """B>1 mixing: empty mask, < min_num pixels, a multi-class mask (byte values 2 count double in
+    foreground_num, ransac_voting_gpu.py:125-129) and a normal image."""
+    from clean_pvnet_amd import ransac_voting as ext
+    d, mask, vertex, idxs, hn, tn = _v3_case(oracle, synth, gpu, "cfg1", 5)
+    mask[0] = 0
+    mask[1] = 0
+    mask[1, 10, 10:14] = 1                               # 4 px < min_num=5 -> skipped
+    mask[2] = 0
+    mask[2, 20, 20:23] = 2                               # 3 px, byte-sum 6 >= 5 -> NOT skipped
+    mask[3][mask[3] != 0] = 3
+    tn = [int(x) for x in (mask != 0).sum((1, 2))]
+    idxs = synth.make_idxs(tn, hn, 4, seed=99)
+    out, win, tnn, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), hn, 0.99, 5, 30000, idxs.to(gpu), None, 0,
+                                              ext.SINGULAR_ZERO)
+    want, det = _check_v3(oracle, out, win, tnn, mask, vertex, idxs, hn, 0.99, singular="zero")
+    assert (want[0] == 0).all() and (want[1] == 0).all()
+    assert det[0]["skipped"] and det[1]["skipped"] and not det[2]["skipped"]
+    assert _np(tnn).tolist() == [0, 0, 3, tn[3], tn[4]]
+
+
+@pytest.mark.parametrize("singular", ["reference", "zero"])
+def test_v3_singular_keypoint_policies(oracle, synth, pkg, gpu, singular):
+    """A keypoint nobody votes for (count 0 -> winner (0,0) -> ATA = 0): reference policy turns the
+    whole image into ATb (b_inv's identity fallback), 'zero' only that keypoint."""
+    from clean_pvnet_amd.ransac_voting_gpu import ransac_voting_layer, ransac_voting_layer_v3
+    d, mask, vertex, idxs, hn, tn = _v3_case(oracle, synth, gpu, "cfg1", 2)
+    vertex[0, :, :, 1, :] = 0.0                          # zero directions: norm1 < 1e-6 everywhere
+    m, v, i = mask.to(gpu), vertex.to(gpu), idxs.to(gpu)
+    got = ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, idxs=i, singular=singular)
+    det = []
+    want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, 0.99, idxs=_np(idxs), singular=singular, details=det)
+    assert det[0]["singular"][1] == 1 and det[0]["win_counts"][1] == 0
+    if singular == "reference":
+        np.testing.assert_allclose(_np(got), want, rtol=1e-6, atol=ATOL)       # ATb is huge: relative
+        assert np.abs(want[0]).max() > 1e3
+    else:
+        np.testing.assert_allclose(_np(got), want, rtol=0, atol=ATOL)
+        assert (want[0, 1] == 0).all() and np.abs(want[0, 0] - _np(d["kpt_2d"])[0, 0]).max() < 2
+    v1 = ransac_voting_layer(m, v, hn, inlier_thresh=0.99, idxs=i)             # v1: whole image zeros
+    assert (_np(v1)[0] == 0).all()
+    np.testing.assert_allclose(_np(v1)[1], want[1], rtol=0, atol=ATOL)
+
+
+def test_v3_subsample_with_injected_selection(oracle, synth, pkg, gpu):
+    """foreground_num > max_num (ransac_voting_gpu.py:135-138) with the U(0,1) draws injected."""
+    from clean_pvnet_amd import ransac_voting as ext
+    c = {**synth.CONFIGS["cfg1"], "B": 2, "fg": 0.3}
+    d = synth.make_batch(**c, seed=5)
+    mask, vertex = d["mask"], d["vertex"]
+    max_num = 1500
+    g = torch.Generator().manual_seed(3)
+    selection = torch.rand(mask.shape, generator=g)
+    fg = mask.sum((1, 2)).float()
+    assert (fg > max_num).all()
+    kept = (mask != 0) & (selection < (torch.tensor(float(max_num)) / fg).view(-1, 1, 1))
+    tn = [int(x) for x in kept.sum((1, 2))]
+    hn = 64
+    idxs = synth.make_idxs(tn, hn, c["K"], seed=5)
+    out, win, tnn, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), hn, 0.99, 5, max_num, idxs.to(gpu),
+                                              selection.to(gpu), 0, ext.SINGULAR_REFERENCE)
+    assert _np(tnn).tolist() == tn
+    _check_v3(oracle, out, win, tnn, mask, vertex, idxs, hn, 0.99, selection=selection, max_num=max_num)
+    # device RNG instead of the injected draws: statistically the same subsample size
+    out_r, _w, tn_r, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), hn, 0.99, 5, max_num, None, None, 12345,
+                                                ext.SINGULAR_REFERENCE)
+    assert np.abs(_np(tn_r) - max_num).max() < 6 * np.sqrt(max_num)
+    assert np.abs(_np(out_r) - _np(d["kpt_2d"])).max() < 2.0
+
+
+# --------------------------------------------------------------------------------------------------
+# estimate_voting_distribution_with_mean
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,B,round_hyp,min_hyp", [("cfg1", 2, 64, 256), ("cfg2", 1, 256, 4096)])
+def test_estimate_parity(oracle, synth, pkg, gpu, cfg, B, round_hyp, min_hyp):
+    from clean_pvnet_amd.ransac_voting_gpu import estimate_voting_distribution_with_mean
+    c = {**synth.CONFIGS[cfg], "B": B}
+    d = synth.make_batch(**c, seed=77)
+    mask, vertex = d["mask"], d["vertex"]
+    if B > 1:
+        mask[1][mask[1] != 0] = 2                        # class 2: `mask == 1` is empty -> skipped image
+    tn = [int(x) for x in (mask == 1).sum((1, 2))]
+    idxs = synth.make_idxs(tn, min_hyp, c["K"], seed=77)
+    mean = d["kpt_2d"] + 0.25
+    det = []
+    _m, want = oracle.estimate_voting_distribution_with_mean(_np(mask), _np(vertex), _np(mean), round_hyp, min_hyp,
+                                                             idxs=_np(idxs), details=det)
+    m, v, mu, i = mask.to(gpu), vertex.to(gpu), mean.to(gpu), idxs.to(gpu)
+    ret_mean, cov, hyp, ratio = estimate_voting_distribution_with_mean(m, v, mu, round_hyp, min_hyp, idxs=i,
+                                                                      output_hyp=True)
+    assert ret_mean is mu and cov.shape == (B, c["K"], 2, 2)
+    np.testing.assert_allclose(_np(cov), want, rtol=1e-4, atol=ATOL)
+    r0 = det[0]
+    np.testing.assert_array_equal(_np(hyp[0]).view(np.uint32), r0["hypo_pts"].transpose(1, 0, 2).view(np.uint32))
+    want_ratio = (r0["counts"].astype(np.float32) / np.float32(r0["tn"])).T
+    np.testing.assert_array_equal(_np(ratio[0]), want_ratio)
+    # raw C ABI: same covariance, bit-exact counts
+    cov2, hyp2, counts2, tn2 = capi.estimate(m, v, mu, min_hyp, 0.99, idxs=i)
+    np.testing.assert_array_equal(_np(cov2), _np(cov))
+    np.testing.assert_array_equal(_np(counts2[0]), r0["counts"].T)
+    assert _np(tn2).tolist() == tn
+
+
+# --------------------------------------------------------------------------------------------------
+# full-size, size-independent properties (BASELINE configs 3-5)
+# --------------------------------------------------------------------------------------------------
+def test_full_size_cfg3_properties_and_sampled_oracle(oracle, synth, pkg, gpu):
+    """B=64, 480x640, K=9, 512 hypotheses on one GPU: (i) three sampled images against the oracle,
+    (ii) permuting the batch permutes the result, (iii) run-to-run determinism, (iv) fused counts ==
+    legacy vote + sum for one image."""
+    from clean_pvnet_amd import ransac_voting as ext
+    c = synth.CONFIGS["cfg3"]
+    d = synth.make_batch(**c, device=gpu)
+    mask, vertex = d["mask"], d["vertex"]
+    tn = [int(x) for x in (mask != 0).sum((1, 2)).cpu()]
+    idxs = synth.make_idxs(tn, c["hn"], c["K"]).to(gpu)
+    out, win, tnn, _ws = ext.ransac_voting_v3(mask, vertex, c["hn"], 0.99, 5, 30000, idxs, None, 0, ext.SINGULAR_REFERENCE)
+    assert _np(tnn).tolist() == tn
+    assert np.abs(_np(out) - _np(d["kpt_2d"])).max() < 2.0
+    for bi in (0, 31, 63):
+        det = []
+        want = oracle.ransac_voting_layer_v3(_np(mask[bi:bi + 1]), _np(vertex[bi:bi + 1]), c["hn"], 0.99,
+                                             idxs=_np(idxs[bi:bi + 1]), details=det)
+        np.testing.assert_array_equal(_np(win[bi]), det[0]["win_counts"])
+        np.testing.assert_allclose(_np(out[bi:bi + 1]), want, rtol=0, atol=ATOL)
+    perm = torch.randperm(c["B"], generator=torch.Generator().manual_seed(1)).to(gpu)
+    out_p, win_p, _t, _w = ext.ransac_voting_v3(mask[perm], vertex[perm], c["hn"], 0.99, 5, 30000, idxs[perm], None, 0,
+                                                ext.SINGULAR_REFERENCE)
+    np.testing.assert_array_equal(_np(out_p), _np(out[perm]))
+    np.testing.assert_array_equal(_np(win_p), _np(win[perm]))
+    out_2, _w2, _t2, _ws2 = ext.ransac_voting_v3(mask, vertex, c["hn"], 0.99, 5, 30000, idxs, None, 0, ext.SINGULAR_REFERENCE)
+    np.testing.assert_array_equal(_np(out_2), _np(out))
+
+
+@pytest.mark.parametrize("cfg,B", [("cfg4", 4), ("cfg5", 2)])
+def test_stress_configs_sampled_oracle(oracle, synth, pkg, gpu, cfg, B):
+    """cfg4 (sparse/occluded, 1024 hyps, outlier pixels) and cfg5 (540x720, K=17, 2048 hyps, tn capped by
+    max_num=30000 -> subsampling with injected draws) at reduced batch, full image size."""
+    from clean_pvnet_amd import ransac_voting as ext
+    c = {**synth.CONFIGS[cfg], "B": B}
+    d = synth.make_batch(**c, seed=4321)
+    mask, vertex = d["mask"], d["vertex"]
+    selection = torch.rand(mask.shape, generator=torch.Generator().manual_seed(8))
+    fg = mask.sum((1, 2)).float()
+    keep = (mask != 0) & ((fg <= 30000).view(-1, 1, 1) | (selection < (torch.tensor(30000.0) / fg).view(-1, 1, 1)))
+    tn = [int(x) for x in keep.sum((1, 2))]
+    if cfg == "cfg5":
+        assert (fg > 30000).all()
+    idxs = synth.make_idxs(tn, c["hn"], c["K"], seed=4321)
+    out, win, tnn, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), c["hn"], 0.99, 5, 30000, idxs.to(gpu),
+                                              selection.to(gpu), 0, ext.SINGULAR_REFERENCE)
+    assert _np(tnn).tolist() == tn
+    _check_v3(oracle, out[:1], win[:1], tnn[:1], mask[:1], vertex[:1], idxs[:1], c["hn"], 0.99, selection=selection[:1])
