@@ -214,7 +214,7 @@ def test_v3_parity_pybind_and_cabi(oracle, synth, pkg, gpu, cfg, B, planar, mask
     out, win, tnn, _ws = ext.ransac_voting_v3(mm, v, hn, 0.99, 5, 30000, i, None, 0, ext.SINGULAR_REFERENCE)
     want, _ = _check_v3(oracle, out, win, tnn, mask, vertex, idxs, hn, 0.99)
     # voting recovers the keypoints the field was built from (compute_vertex known answer)
-    assert np.abs(want - _np(d["kpt_2d"])).max() < 2.0
+    assert np.abs(want - _np(d["kpt_2d"])).max() < 6.0   # sigma=0.05 rad noise, keypoints up to ~100 px away
     out2, win2, tn2 = capi.v3(mm, v, hn, 0.99, idxs=i)
     np.testing.assert_array_equal(_np(out2), _np(out))
     np.testing.assert_array_equal(_np(win2), _np(win))
@@ -232,7 +232,7 @@ def test_v3_python_layer_matches_reference_signature_use(oracle, synth, pkg, gpu
     # free-running RNG forms: statistical parity = known-answer recovery
     torch.manual_seed(0)
     mean_r = ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.99)
-    assert np.abs(_np(mean_r) - _np(d["kpt_2d"])).max() < 2.0
+    assert np.abs(_np(mean_r) - _np(d["kpt_2d"])).max() < 6.0
     torch.manual_seed(0)
     np.testing.assert_array_equal(_np(ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.99)), _np(mean_r))
     mean2, var = estimate_voting_distribution_with_mean(m, v, mean_r)
@@ -317,7 +317,7 @@ def test_v3_subsample_with_injected_selection(oracle, synth, pkg, gpu):
     out_r, _w, tn_r, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), hn, 0.99, 5, max_num, None, None, 12345,
                                                 ext.SINGULAR_REFERENCE)
     assert np.abs(_np(tn_r) - max_num).max() < 6 * np.sqrt(max_num)
-    assert np.abs(_np(out_r) - _np(d["kpt_2d"])).max() < 2.0
+    assert np.abs(_np(out_r) - _np(d["kpt_2d"])).max() < 6.0
 
 
 # --------------------------------------------------------------------------------------------------
@@ -368,7 +368,7 @@ def test_full_size_cfg3_properties_and_sampled_oracle(oracle, synth, pkg, gpu):
     idxs = synth.make_idxs(tn, c["hn"], c["K"]).to(gpu)
     out, win, tnn, _ws = ext.ransac_voting_v3(mask, vertex, c["hn"], 0.99, 5, 30000, idxs, None, 0, ext.SINGULAR_REFERENCE)
     assert _np(tnn).tolist() == tn
-    assert np.abs(_np(out) - _np(d["kpt_2d"])).max() < 2.0
+    assert np.abs(_np(out) - _np(d["kpt_2d"])).max() < 6.0
     for bi in (0, 31, 63):
         det = []
         want = oracle.ransac_voting_layer_v3(_np(mask[bi:bi + 1]), _np(vertex[bi:bi + 1]), c["hn"], 0.99,
