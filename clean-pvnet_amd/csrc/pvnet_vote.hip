@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "pvnet_vote.h"
@@ -238,7 +239,36 @@ struct VertexArgs {
     int64_t sb, sh, sw, sk, sc;
     int K;
     int vec2;  // sc == 1 and every other stride even: (x,y) is one aligned 8-byte load
+    double kappa;  // thresh / sqrt(1 - thresh^2) for the fast-path records, 0 = no records
 };
+
+// Per (image, keypoint, compacted pixel) record of the fast inlier test, 32 bytes = one
+// s_load_dwordx8 in the count kernel:
+//   lo = (cx, cy, nhx, nhy)   nh = n / |n|  (binary64 quotient rounded once)
+//   hi = (Bx, By, nx, ny)     B  = kappa * perp(nh); (nx,ny) raw, for the exact fallback
+// A pixel the exact test can never accept (K:121: norm1 < 1e-6, or a non-finite norm1) gets
+// cx = +inf, nh = (1,0), B = (1,0): then a = b' = -inf, t = a - |b'| = -inf (never an inlier) and the
+// ambiguity measure is +inf (never flagged).
+struct __attribute__((aligned(32))) PixelRec {
+    float4 lo, hi;
+};
+
+__device__ __forceinline__ PixelRec make_record(float cx, float cy, float nx, float ny, double kappa)
+{
+    PixelRec r;
+    float norm1 = sqrtf(nx * nx + ny * ny);           // the exact path's own norm1 (K:116)
+    bool ok = !lt_1e6(norm1) && norm1 < INFINITY && norm1 == norm1;
+    if (ok) {
+        double N1 = sqrt((double)nx * (double)nx + (double)ny * (double)ny);
+        double ux = (double)nx / N1, uy = (double)ny / N1;
+        r.lo = make_float4(cx, cy, (float)ux, (float)uy);
+        r.hi = make_float4((float)(-kappa * uy), (float)(kappa * ux), nx, ny);
+    } else {
+        r.lo = make_float4(INFINITY, 0.f, 1.f, 0.f);
+        r.hi = make_float4(1.f, 0.f, nx, ny);
+    }
+    return r;
+}
 
 // Ordered scatter: pixel -> row r of the image's compacted list; writes coords[b][r] = (x,y)
 // (P:140-141) and dirs[b][vi][r] = vertex[b,y,x,vi,:] (P:142-143, stored planar per keypoint so
@@ -249,7 +279,8 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
                                                     const int *__restrict__ tile_sum,
                                                     int *__restrict__ tn_out,
                                                     float2 *__restrict__ coords,
-                                                    float2 *__restrict__ dirs)
+                                                    float2 *__restrict__ dirs,
+                                                    PixelRec *__restrict__ recs)
 {
     __shared__ long long redl[4];
     __shared__ int red[4];
@@ -322,6 +353,8 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
                 d.y = src[(int64_t)vi * v.sk + v.sc];
             }
             dirs[((size_t)b * v.K + vi) * a.cap + r] = d;
+            if (v.kappa != 0.0)
+                recs[((size_t)b * v.K + vi) * a.cap + r] = make_record((float)x, (float)y, d.x, d.y, v.kappa);
         }
     }
 }
@@ -488,6 +521,170 @@ __global__ __launch_bounds__(kBlock) void k_count_inliers(CountArgs a)
         for (int r = 0; r < R; ++r) {
             int h = ht * HT + r * 64 + lane;
             if (h < a.hn && cnt[r] != 0) atomicAdd(&a.counts[hbase + (long long)h * a.h_h], cnt[r]);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Stage 3, fast form.  Same mapping (lanes are hypotheses, R per lane) but:
+//   * the pixel arrives as a 32-byte PixelRec through a SCALAR load (s_load_dwordx8): zero VALU
+//     cycles, the operands of every evaluation are VGPR(hypothesis) x SGPR(pixel);
+//   * hypotheses are processed in PAIRS with packed fp32 (v_pk_add/mul/fma_f32: two evaluations per
+//     issue slot -- measured 4.2 cycles per packed wave-instruction vs 4.1 for a scalar v_fma_f32 on
+//     gfx950, tools/microbench);
+//   * no sqrt, no divide.  With d = h - c (the SAME rounded subtraction as the exact path),
+//     nh = n/|n| and kappa = T/sqrt(1-T^2):
+//         a  = d . nh            = |d| cos(theta)
+//         b' = kappa * d x nh    = kappa |d| sin(theta)
+//         cos(theta) > T  <=>  t := a - |b'| > 0
+//   * the decision is taken from t only when it is OUTSIDE a guard band,  |t| - beta*a > eps_abs;
+//     inside it (about 3e-6 of all evaluations) the pixel is re-evaluated with the exact binary32
+//     sequence of K:100-125 and the counters are corrected.  Derivation of beta:
+//     the exact path's computed cosine deviates from the true one by <= 8u (u = 2^-24), which is
+//     |d| 8u/(1-T^2) in t; the fast path's t deviates by <= 3u(1+kappa)|d|; a ~ T|d| in the band.
+//     eps_abs covers the exact path's norm2 < 1e-6 reject (K:121): |d| <= 1e-6 => |t| <= (1+kappa)|d|.
+//   * hypotheses that are not finite or beyond 1e15 px (where the exact path's squares overflow and
+//     the bounds above stop holding) send the whole work item down the exact loop.
+// Inlier counts stay bit-exact against the oracle; tests/test_gpu_parity.py hammers the band.
+// ---------------------------------------------------------------------------------------------
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float8v __attribute__((ext_vector_type(8)));
+
+struct FastConsts {
+    float beta;     // relative half-width of the guard band (in units of a)
+    float eps_abs;  // absolute floor of the band, px
+};
+
+// (a, b') of one hypothesis pair against the pixel held in SGPRs.  cxy=(cx,cy), nh=(nhx,nhy), Bv=(Bx,By).
+__device__ __forceinline__ void pk_project(float2v hx2, float2v hy2, float2v cxy, float2v nh, float2v Bv,
+                                           float2v &a2, float2v &b2)
+{
+    float2v dx2, dy2, p2, q2;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dx2) : "v"(hx2), "s"(cxy));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dy2) : "v"(hy2), "s"(cxy));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(p2) : "v"(dy2), "s"(nh));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(a2) : "v"(dx2), "s"(nh), "v"(p2));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(q2) : "v"(dy2), "s"(Bv));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(b2) : "v"(dx2), "s"(Bv), "v"(q2));
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_count_fast(
+    const float8v *__restrict__ recs /*[B,K,cap]*/, const float2 *__restrict__ hyps /*[B,K,hn]*/,
+    int *__restrict__ counts /*[B,K,hn]*/, const int *__restrict__ tn_arr, int B, int K, int hn, int cap,
+    float thresh, FastConsts fc)
+{
+    static_assert(R % 2 == 0, "hypotheses are processed in pairs");
+    __shared__ int item_end[kMaxBatchLds];
+    const int lane = lane_id(), wave = wave_id();
+    constexpr int HT = 64 * R;
+    constexpr int PC = 4 * kPixPerWave;
+    const int nht = (hn + HT - 1) / HT;
+    const int per_chunk = K * nht;
+
+    if (wave == 0) {
+        int carry = 0;
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            int b = b0 + lane;
+            int n = 0;
+            if (b < B) n = ((tn_arr[b] + PC - 1) / PC) * per_chunk;
+            int inc = n;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int m = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += m;
+            }
+            inc += carry;
+            if (b < B) item_end[b] = inc;
+            carry = __builtin_amdgcn_readlane(inc, 63);
+        }
+    }
+    __syncthreads();
+    const int total = item_end[B - 1];
+
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        int lo = 0, hi = B - 1;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (item_end[mid] > item) hi = mid; else lo = mid + 1;
+        }
+        const int b = __builtin_amdgcn_readfirstlane(lo);
+        const int local = __builtin_amdgcn_readfirstlane(item - (b ? item_end[b - 1] : 0));
+        const int chunk = local / per_chunk;
+        const int rem = local - chunk * per_chunk;
+        const int vi = rem / nht;
+        const int ht = rem - vi * nht;
+        const int tn = __builtin_amdgcn_readfirstlane(tn_arr[b]);
+        const int bk = b * K + vi;
+
+        // this lane's R hypotheses; lanes past hn get (0,0) and never write their counters
+        float2v hx2[R / 2], hy2[R / 2];
+        int cnt[R];
+        bool far = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int h = ht * HT + r * 64 + lane;
+            float2 hp = make_float2(0.f, 0.f);
+            if (h < hn) hp = hyps[(size_t)bk * hn + h];
+            hx2[r / 2][r & 1] = hp.x;
+            hy2[r / 2][r & 1] = hp.y;
+            cnt[r] = 0;
+            far |= !(fabsf(hp.x) < 1e15f && fabsf(hp.y) < 1e15f);
+        }
+        const int p0 = chunk * PC + wave * kPixPerWave;
+        const int p1 = min(tn, p0 + kPixPerWave);
+        const float8v *rp = recs + (size_t)bk * cap;
+
+        if (__builtin_expect(__any(far), 0)) {
+            // exact loop (K:100-125) for the whole work item
+            for (int p = p0; p < p1; ++p) {
+                const float8v rec = rp[p];
+                const float cx = rec[0], cy = rec[1], nx = rec[6], ny = rec[7];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    cnt[r] += vote_exact(cx, cy, hx2[r / 2][r & 1], hy2[r / 2][r & 1], nx, ny, thresh) ? 1 : 0;
+            }
+        } else {
+            for (int p = p0; p < p1; ++p) {
+                const float8v rec = rp[p];     // wave-uniform address -> scalar load
+                const float2v cxy = {rec[0], rec[1]}, nh = {rec[2], rec[3]}, Bv = {rec[4], rec[5]};
+                float zmin = INFINITY;
+#pragma unroll
+                for (int q = 0; q < R / 2; ++q) {
+                    float2v a2, b2;
+                    pk_project(hx2[q], hy2[q], cxy, nh, Bv, a2, b2);
+                    const float t0 = a2[0] - fabsf(b2[0]);
+                    const float t1 = a2[1] - fabsf(b2[1]);
+                    cnt[2 * q] += t0 > 0.f ? 1 : 0;
+                    cnt[2 * q + 1] += t1 > 0.f ? 1 : 0;
+                    const float z0 = __builtin_fmaf(-fc.beta, a2[0], fabsf(t0));
+                    const float z1 = __builtin_fmaf(-fc.beta, a2[1], fabsf(t1));
+                    zmin = fminf(zmin, fminf(z0, z1));
+                }
+                if (__builtin_expect(__any(zmin <= fc.eps_abs), 0)) {
+                    // some evaluation of this pixel sits inside the guard band: replace the fast
+                    // decisions of the pixel by the exact ones
+                    const float cx = rec[0], cy = rec[1], nx = rec[6], ny = rec[7];
+#pragma unroll
+                    for (int q = 0; q < R / 2; ++q) {
+                        float2v a2, b2;
+                        pk_project(hx2[q], hy2[q], cxy, nh, Bv, a2, b2);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const float t = a2[e] - fabsf(b2[e]);
+                            const int fast = t > 0.f ? 1 : 0;
+                            const int exact = vote_exact(cx, cy, hx2[q][e], hy2[q][e], nx, ny, thresh) ? 1 : 0;
+                            cnt[2 * q + e] += exact - fast;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int h = ht * HT + r * 64 + lane;
+            if (h < hn && cnt[r] != 0) atomicAdd(&counts[(size_t)bk * hn + h], cnt[r]);
         }
     }
 }
@@ -766,7 +963,7 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
     int T;
-    size_t tile_nz, tile_sum, tn, coords, dirs, hyps, counts, sums, singular, pts, total;
+    size_t tile_nz, tile_sum, tn, coords, dirs, recs, hyps, counts, sums, singular, pts, total;
 };
 
 Layout make_layout(const pvv_problem *p)
@@ -781,6 +978,7 @@ Layout make_layout(const pvv_problem *p)
     L.tn = take(sizeof(int) * (size_t)p->B);
     L.coords = take(sizeof(float2) * (size_t)p->B * p->cap);
     L.dirs = take(sizeof(float2) * (size_t)p->B * p->K * p->cap);
+    L.recs = take(sizeof(PixelRec) * (size_t)p->B * p->K * p->cap);
     L.hyps = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
     L.counts = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
     L.sums = take(sizeof(double) * (size_t)p->B * p->K * 5);
@@ -836,6 +1034,53 @@ int launch_count(const CountArgs &a, hipStream_t st)
     return check_launch("k_count_inliers");
 }
 
+// The fast test needs 0 < T < 1 with a sane kappa; outside [0.5, 0.99995] (and when PVV_COUNT_KERNEL=exact
+// is set, for A/B runs) the exact kernel is used.
+bool use_fast_count(float thresh)
+{
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("PVV_COUNT_KERNEL");
+        forced = (e && !strcmp(e, "exact")) ? 1 : 0;
+    }
+    return !forced && thresh >= 0.5f && thresh <= 0.99995f;
+}
+
+double fast_kappa(float thresh)
+{
+    if (!use_fast_count(thresh)) return 0.0;
+    const double T = (double)thresh;
+    return T / std::sqrt(1.0 - T * T);
+}
+
+FastConsts fast_consts(float thresh)
+{
+    const double T = (double)thresh, s2 = 1.0 - T * T, kappa = T / std::sqrt(s2);
+    const double u = 0x1p-24;
+    FastConsts fc;
+    fc.beta = (float)(1.25 * (3.0 * (1.0 + kappa) + 8.0 / s2) * u / T);
+    fc.eps_abs = (float)(1.5e-6 * (1.0 + kappa));
+    return fc;
+}
+
+int launch_count_fast(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st)
+{
+    const int grid = num_cus() * 8;
+    const float8v *recs = (const float8v *)(ws + L.recs);
+    const float2 *hyps = (const float2 *)(ws + L.hyps);
+    int *counts = (int *)(ws + L.counts);
+    const int *tn = (const int *)(ws + L.tn);
+    const FastConsts fc = fast_consts(p->inlier_thresh);
+#define PVV_LAUNCH_FAST(R)                                                                             \
+    hipLaunchKernelGGL(k_count_fast<R>, dim3(grid), dim3(kBlock), 0, st, recs, hyps, counts, tn, p->B, \
+                       p->K, p->hn, p->cap, p->inlier_thresh, fc)
+    if (p->hn <= 128) PVV_LAUNCH_FAST(2);
+    else if (p->hn <= 256) PVV_LAUNCH_FAST(4);
+    else PVV_LAUNCH_FAST(8);
+#undef PVV_LAUNCH_FAST
+    return check_launch("k_count_fast");
+}
+
 CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
 {
     CountArgs a;
@@ -865,7 +1110,7 @@ int launch_compaction(const MaskArgs &m, const VertexArgs &v, const Layout &L, c
     if (int e = check_launch("k_tile_recount")) return e;
     hipLaunchKernelGGL(k_compact<ES>, grid, block, 0, st, m, v, (const int *)tile_nz,
                        (const int *)tile_sum, (int *)(ws + L.tn), (float2 *)(ws + L.coords),
-                       (float2 *)(ws + L.dirs));
+                       (float2 *)(ws + L.dirs), (PixelRec *)(ws + L.recs));
     return check_launch("k_compact");
 }
 
@@ -889,6 +1134,7 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
     v.sb = p->vertex_stride[0]; v.sh = p->vertex_stride[1]; v.sw = p->vertex_stride[2];
     v.sk = p->vertex_stride[3]; v.sc = p->vertex_stride[4];
     v.K = p->K;
+    v.kappa = fast_kappa(p->inlier_thresh);
     v.vec2 = (v.sc == 1 && !(v.sb & 1) && !(v.sh & 1) && !(v.sw & 1) && !(v.sk & 1) &&
               ((uintptr_t)d_vertex % 8 == 0)) ? 1 : 0;
     int e;
@@ -906,6 +1152,7 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
                        (const float2 *)(ws + L.dirs), (float2 *)(ws + L.hyps), (int *)(ws + L.counts),
                        p->B, p->K, p->hn, p->cap, p->seed);
     if ((e = check_launch("k_gen_hypothesis"))) return e;
+    if (use_fast_count(p->inlier_thresh)) return launch_count_fast(p, L, ws, st);
     return launch_count(planar_count_args(p, L, ws), st);
 }
 
@@ -999,7 +1246,7 @@ PVV_EXPORT int pvv_estimate_voting_distribution(const pvv_problem *p, const void
 }
 
 PVV_EXPORT int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace, size_t workspace_bytes,
-                                      void *stream)
+                                      int zero_counts, void *stream)
 {
     if (int e = validate(p)) return e;
     if (!d_workspace) return fail(PVV_E_ARG, "workspace is NULL");
@@ -1007,8 +1254,11 @@ PVV_EXPORT int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace, s
     if (workspace_bytes < L.total) return fail(PVV_E_WORKSPACE, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)d_workspace;
-    hipError_t e = hipMemsetAsync(ws + L.counts, 0, sizeof(int) * (size_t)p->B * p->K * p->hn, st);
-    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    if (zero_counts) {
+        hipError_t e = hipMemsetAsync(ws + L.counts, 0, sizeof(int) * (size_t)p->B * p->K * p->hn, st);
+        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+    if (use_fast_count(p->inlier_thresh)) return launch_count_fast(p, L, ws, st);
     return launch_count(planar_count_args(p, L, ws), st);
 }
 

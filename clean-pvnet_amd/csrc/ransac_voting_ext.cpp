@@ -279,11 +279,12 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> estimate_voting_distr
 // Re-run only the inlier-count kernel on the state a previous ransac_voting_v3 call left in `ws`
 // (bench.py brackets this with HIP events to get the dominant kernel's duration).
 void rerun_count_kernel(at::Tensor mask, at::Tensor vertex, int64_t hn, double inlier_thresh, int64_t min_num,
-                        int64_t max_num, at::Tensor ws)
+                        int64_t max_num, at::Tensor ws, bool zero_counts)
 {
     pvv_problem p = make_problem(mask, vertex, hn, inlier_thresh, min_num, max_num, 0, 0);
     check_dev(ws, "workspace", at::kByte);
-    ok(pvv_rerun_count_kernel(&p, ws.data_ptr(), (size_t)ws.numel(), cur_stream(vertex)), "rerun_count_kernel");
+    ok(pvv_rerun_count_kernel(&p, ws.data_ptr(), (size_t)ws.numel(), zero_counts ? 1 : 0, cur_stream(vertex)),
+       "rerun_count_kernel");
 }
 
 }  // namespace

@@ -1,0 +1,44 @@
+"""Batch sharding over the GPUs of a node + the one exchange step of the path.
+
+Images are independent units (the reference already loops ``for bi in range(b)``,
+ransac_voting_gpu.py:123,205), so the batch shards as contiguous chunks with no data-path collective;
+the only exchange is one all_gather of the per-image results (72 B of means + 144 B of covariance
+per image -- latency-bound, xGMI bandwidth never matters).  One process per GPU, ``torch.distributed``
+backend ``nccl`` (= RCCL on ROCm); the same code runs on ``gloo`` for the CPU tests.  The reference
+has no counterpart (its only multi-GPU mechanism is nn.DataParallel for training, trainer.py:10-12).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(batch, world_size, rank):
+    """Contiguous chunk ``[lo, hi)`` of a batch owned by ``rank``: ceil(batch/world) images per rank,
+    trailing ranks may own fewer (or none)."""
+    per = -(-batch // world_size)
+    lo = min(batch, rank * per)
+    return lo, min(batch, lo + per)
+
+
+def gather_results(local, batch, group=None):
+    """all_gather per-image results ``[b_local, ...]`` -> ``[batch, ...]`` on every rank, in batch order.
+
+    Chunks are padded to ceil(batch/world) rows so one ``all_gather_into_tensor`` moves everything."""
+    if not (dist.is_available() and dist.is_initialized()):
+        assert local.shape[0] == batch
+        return local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per = -(-batch // world)
+    lo, hi = shard_bounds(batch, world, rank)
+    assert local.shape[0] == hi - lo, "rank %d owns images [%d,%d) but got %d rows" % (rank, lo, hi, local.shape[0])
+    pad = local.new_zeros((per,) + tuple(local.shape[1:]))
+    pad[: hi - lo] = local
+    out = local.new_empty((world * per,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    return out[:batch]
+
+
+def sharded_vote(vote_fn, mask_local, vertex_local, batch, *args, group=None, **kwargs):
+    """Run ``vote_fn`` (e.g. ``ransac_voting_layer_v3``) on this rank's shard and gather ``[batch,vn,2]``."""
+    local = vote_fn(mask_local, vertex_local, *args, **kwargs)
+    return gather_results(local, batch, group)

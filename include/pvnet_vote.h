@@ -153,9 +153,12 @@ int pvv_estimate_voting_distribution(const pvv_problem *p, const void *d_mask,
 
 /* Bench / profiling aid: re-runs ONLY the inlier-count kernel of the last
  * layer call recorded in `d_workspace` (same problem), so its duration can be
- * bracketed with HIP events on `stream`. */
+ * bracketed with HIP events on `stream`.  zero_counts != 0 first clears the
+ * counters (a separate memset node) so the result stays valid; with 0 nothing
+ * but the kernel is enqueued and the counters keep accumulating. */
 int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace,
-                           size_t workspace_bytes, void *stream);
+                           size_t workspace_bytes, int zero_counts,
+                           void *stream);
 
 #ifdef __cplusplus
 }

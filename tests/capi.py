@@ -48,7 +48,7 @@ def load():
         L.pvv_ransac_voting_v3.argtypes = [ctypes.POINTER(Problem), vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]
         L.pvv_estimate_voting_distribution.argtypes = [ctypes.POINTER(Problem), vp, vp, vp, vp, vp, vp, sz,
                                                        vp, vp, vp, vp, vp]
-        L.pvv_rerun_count_kernel.argtypes = [ctypes.POINTER(Problem), vp, sz, vp]
+        L.pvv_rerun_count_kernel.argtypes = [ctypes.POINTER(Problem), vp, sz, ctypes.c_int, vp]
         _lib = L
     return _lib
 
