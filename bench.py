@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--config", default="cfg3", help="image shape / K / hn / foreground of this BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", action="store_true",
+                    help="also time config 2 (B=1 latency) and v3+estimate; off by default so that a rocprofv3 "
+                         "--stats run of the default command sees the count kernel at ONE problem size")
     ap.add_argument("--cpu-sample", type=int, default=4, help="images timed on the CPU oracle")
     args = ap.parse_args()
 
@@ -136,7 +139,7 @@ def main():
                     "evaluations": evals, "gevals_per_s": round(evals / (k_avg_ms * 1e-3) / 1e9, 1)}
 
         extra = {"tn_mean": round(float(tn_cpu.float().mean()), 1), "known_answer_max_err_px": round(err, 3)}
-        if world == 1:
+        if world == 1 and args.extras:
             # config 2: latency of one 480x640 image (B = 1), same call
             m1, v1 = mask[:1], vertex[:1]
             for _ in range(10):

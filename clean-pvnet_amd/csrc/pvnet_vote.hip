@@ -569,19 +569,44 @@ __device__ __forceinline__ void pk_project(float2v hx2, float2v hy2, float2v cxy
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(b2) : "v"(dx2), "s"(Bv), "v"(q2));
 }
 
+// t = a - |b|: one v_sub_f32 with an abs source modifier (f32 add/sub issue in 2.4 cycles on gfx950, every
+// other VALU op in ~4.2).  Kept as asm so the SLP vectoriser cannot turn two of them into
+// v_and + v_and + v_pk_add.
+__device__ __forceinline__ float sub_abs(float a, float b)
+{
+    float t;
+    asm("v_sub_f32 %0, %1, |%2|" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+
 template <int R>
 __global__ __launch_bounds__(kBlock) void k_count_fast(
     const float8v *__restrict__ recs /*[B,K,cap]*/, const float2 *__restrict__ hyps /*[B,K,hn]*/,
     int *__restrict__ counts /*[B,K,hn]*/, const int *__restrict__ tn_arr, int B, int K, int hn, int cap,
-    float thresh, FastConsts fc)
+    float thresh, FastConsts fc, int max_pix_per_wave, int target_items)
 {
     static_assert(R % 2 == 0, "hypotheses are processed in pairs");
     __shared__ int item_end[kMaxBatchLds];
+    __shared__ int s_ppw;
     const int lane = lane_id(), wave = wave_id();
     constexpr int HT = 64 * R;
-    constexpr int PC = 4 * kPixPerWave;
     const int nht = (hn + HT - 1) / HT;
     const int per_chunk = K * nht;
+
+    // Pixels one wave walks per work item: as many as max_pix_per_wave (amortises the hypothesis loads and
+    // the final atomics) but few enough that the batch still splits into >= target_items items -- a
+    // single 480x640 image must spread over 256 CUs too.  Every block derives the same value from tn[].
+    if (wave == 0) {
+        long long px = 0;
+        for (int b = lane; b < B; b += 64) px += tn_arr[b];
+        px = wave_sum(px) * per_chunk;
+        long long want = px / (4ll * target_items);
+        int ppw = (int)(want < 16 ? 16 : (want > max_pix_per_wave ? max_pix_per_wave : want));
+        if (lane == 0) s_ppw = ppw;
+    }
+    __syncthreads();
+    const int pix_per_wave = __builtin_amdgcn_readfirstlane(s_ppw);
+    const int PC = 4 * pix_per_wave;
 
     if (wave == 0) {
         int carry = 0;
@@ -632,8 +657,8 @@ __global__ __launch_bounds__(kBlock) void k_count_fast(
             cnt[r] = 0;
             far |= !(fabsf(hp.x) < 1e15f && fabsf(hp.y) < 1e15f);
         }
-        const int p0 = chunk * PC + wave * kPixPerWave;
-        const int p1 = min(tn, p0 + kPixPerWave);
+        const int p0 = chunk * PC + wave * pix_per_wave;
+        const int p1 = min(tn, p0 + pix_per_wave);
         const float8v *rp = recs + (size_t)bk * cap;
 
         if (__builtin_expect(__any(far), 0)) {
@@ -645,41 +670,57 @@ __global__ __launch_bounds__(kBlock) void k_count_fast(
                 for (int r = 0; r < R; ++r)
                     cnt[r] += vote_exact(cx, cy, hx2[r / 2][r & 1], hy2[r / 2][r & 1], nx, ny, thresh) ? 1 : 0;
             }
-        } else {
-            for (int p = p0; p < p1; ++p) {
-                const float8v rec = rp[p];     // wave-uniform address -> scalar load
-                const float2v cxy = {rec[0], rec[1]}, nh = {rec[2], rec[3]}, Bv = {rec[4], rec[5]};
-                float zmin = INFINITY;
+        } else if (p1 > p0) {
+            // Counting by sign bit: t < 0 (not an inlier) shifts a 1 into a per-hypothesis bit queue
+            // (one v_alignbit_b32 per evaluation); every 32 pixels the queue is popcounted.  t = +0 is
+            // always inside the guard band, so "sign bit clear" == "fast path says inlier".
+            int neg[R];
 #pragma unroll
-                for (int q = 0; q < R / 2; ++q) {
-                    float2v a2, b2;
-                    pk_project(hx2[q], hy2[q], cxy, nh, Bv, a2, b2);
-                    const float t0 = a2[0] - fabsf(b2[0]);
-                    const float t1 = a2[1] - fabsf(b2[1]);
-                    cnt[2 * q] += t0 > 0.f ? 1 : 0;
-                    cnt[2 * q + 1] += t1 > 0.f ? 1 : 0;
-                    const float z0 = __builtin_fmaf(-fc.beta, a2[0], fabsf(t0));
-                    const float z1 = __builtin_fmaf(-fc.beta, a2[1], fabsf(t1));
-                    zmin = fminf(zmin, fminf(z0, z1));
-                }
-                if (__builtin_expect(__any(zmin <= fc.eps_abs), 0)) {
-                    // some evaluation of this pixel sits inside the guard band: replace the fast
-                    // decisions of the pixel by the exact ones
-                    const float cx = rec[0], cy = rec[1], nx = rec[6], ny = rec[7];
+            for (int r = 0; r < R; ++r) neg[r] = 0;
+            for (int pp = p0; pp < p1; pp += 32) {
+                unsigned acc[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = 0u;
+                const int pe = min(p1, pp + 32);
+                for (int p = pp; p < pe; ++p) {
+                    const float8v rec = rp[p];     // wave-uniform address -> scalar load
+                    const float2v cxy = {rec[0], rec[1]}, nh = {rec[2], rec[3]}, Bv = {rec[4], rec[5]};
+                    float zmin = INFINITY;
 #pragma unroll
                     for (int q = 0; q < R / 2; ++q) {
                         float2v a2, b2;
                         pk_project(hx2[q], hy2[q], cxy, nh, Bv, a2, b2);
+                        const float t0 = sub_abs(a2[0], b2[0]);
+                        const float t1 = sub_abs(a2[1], b2[1]);
+                        acc[2 * q] = __builtin_amdgcn_alignbit(acc[2 * q], __float_as_uint(t0), 31);
+                        acc[2 * q + 1] = __builtin_amdgcn_alignbit(acc[2 * q + 1], __float_as_uint(t1), 31);
+                        const float z0 = __builtin_fmaf(-fc.beta, a2[0], fabsf(t0));
+                        const float z1 = __builtin_fmaf(-fc.beta, a2[1], fabsf(t1));
+                        zmin = fminf(fminf(zmin, z0), z1);     // one v_min3_f32
+                    }
+                    if (__builtin_expect(__any(zmin <= fc.eps_abs), 0)) {
+                        // some evaluation of this pixel sits inside the guard band: replace the fast
+                        // decisions of the pixel by the exact ones
+                        const float cx = rec[0], cy = rec[1], nx = rec[6], ny = rec[7];
 #pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const float t = a2[e] - fabsf(b2[e]);
-                            const int fast = t > 0.f ? 1 : 0;
-                            const int exact = vote_exact(cx, cy, hx2[q][e], hy2[q][e], nx, ny, thresh) ? 1 : 0;
-                            cnt[2 * q + e] += exact - fast;
+                        for (int q = 0; q < R / 2; ++q) {
+                            float2v a2, b2;
+                            pk_project(hx2[q], hy2[q], cxy, nh, Bv, a2, b2);
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const float t = sub_abs(a2[e], b2[e]);
+                                const int fast = (__float_as_uint(t) >> 31) ? 0 : 1;
+                                const int exact = vote_exact(cx, cy, hx2[q][e], hy2[q][e], nx, ny, thresh) ? 1 : 0;
+                                cnt[2 * q + e] += exact - fast;
+                            }
                         }
                     }
                 }
+#pragma unroll
+                for (int r = 0; r < R; ++r) neg[r] += __popc(acc[r]);
             }
+#pragma unroll
+            for (int r = 0; r < R; ++r) cnt[r] += (p1 - p0) - neg[r];
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -1063,17 +1104,39 @@ FastConsts fast_consts(float thresh)
     return fc;
 }
 
+// Persistent grid = exactly the blocks that are co-resident (VGPR-limited), so that no block starts late
+// and drags a tail behind the others.
+template <typename Kern>
+int resident_blocks(Kern kern)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, 0) != hipSuccess || per_cu <= 0)
+        per_cu = 4;
+    if (per_cu > 8) per_cu = 8;
+    return per_cu * num_cus();
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+
 int launch_count_fast(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st)
 {
-    const int grid = num_cus() * 8;
+    // tuning knobs (defaults chosen from sweeps on MI355X)
+    static const int per_cu = env_int("PVV_GRID_PER_CU", 24);
+    static const int ppw = env_int("PVV_PIX_PER_WAVE", 128);
+    static const int items_per_cu = env_int("PVV_ITEMS_PER_CU", 6);
+    const int grid2 = per_cu * num_cus(), grid4 = grid2, grid8 = grid2;
     const float8v *recs = (const float8v *)(ws + L.recs);
     const float2 *hyps = (const float2 *)(ws + L.hyps);
     int *counts = (int *)(ws + L.counts);
     const int *tn = (const int *)(ws + L.tn);
     const FastConsts fc = fast_consts(p->inlier_thresh);
-#define PVV_LAUNCH_FAST(R)                                                                             \
-    hipLaunchKernelGGL(k_count_fast<R>, dim3(grid), dim3(kBlock), 0, st, recs, hyps, counts, tn, p->B, \
-                       p->K, p->hn, p->cap, p->inlier_thresh, fc)
+#define PVV_LAUNCH_FAST(R)                                                                                   \
+    hipLaunchKernelGGL(k_count_fast<R>, dim3(grid##R), dim3(kBlock), 0, st, recs, hyps, counts, tn, p->B, \
+                       p->K, p->hn, p->cap, p->inlier_thresh, fc, ppw, items_per_cu * num_cus())
     if (p->hn <= 128) PVV_LAUNCH_FAST(2);
     else if (p->hn <= 256) PVV_LAUNCH_FAST(4);
     else PVV_LAUNCH_FAST(8);
