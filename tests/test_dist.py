@@ -1,0 +1,78 @@
+"""The N > 1 path on CPU: two gloo ranks shard a batch, each votes on its shard (here with the ORACLE standing in for
+the GPU layer -- tests may do that, the product may not) and the gathered result must equal the unsharded one."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, batch, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import lib
+        lib._register_clean_pvnet_amd()
+        from clean_pvnet_amd import dist as pdist
+        from clean_pvnet_amd import synth
+        from oracle import vote_oracle
+        cfg = {**synth.CONFIGS["cfg1"]}
+        cfg.pop("B")
+        lo, hi = pdist.shard_bounds(batch, world, rank)
+        d = synth.make_batch(B=hi - lo, **cfg, first_index=lo) if hi > lo else None     # each rank makes ITS shard only
+
+        def vote(mask, vertex, hn, **kw):
+            tn = [int(x) for x in (mask != 0).sum((1, 2))]
+            idxs = synth.make_idxs(tn, hn, vertex.shape[3], first_index=lo).numpy()
+            return torch.from_numpy(vote_oracle.ransac_voting_layer_v3(mask.numpy(), vertex.numpy(), hn, 0.99, idxs=idxs))
+
+        if d is not None:
+            out = pdist.sharded_vote(vote, d["mask"], d["vertex"], batch, cfg["hn"])
+        else:
+            out = pdist.gather_results(torch.zeros(0, cfg["K"], 2), batch)
+        cov_local = torch.arange((hi - lo) * cfg["K"] * 4, dtype=torch.float32).view(hi - lo, cfg["K"], 2, 2) + 1000 * rank
+        cov = pdist.gather_results(cov_local, batch)
+        q.put((rank, out.numpy(), cov.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [4, 5])
+def test_two_rank_gloo_sharded_vote_equals_single_process(oracle, synth, batch):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = {**synth.CONFIGS["cfg1"]}
+    cfg.pop("B")
+    d = synth.make_batch(B=batch, **cfg)                                            # the same images, unsharded
+    tn = [int(x) for x in (d["mask"] != 0).sum((1, 2))]
+    idxs = synth.make_idxs(tn, cfg["hn"], cfg["K"]).numpy()
+    want = oracle.ransac_voting_layer_v3(d["mask"].numpy(), d["vertex"].numpy(), cfg["hn"], 0.99, idxs=idxs)
+    for rank, out, cov in got:
+        assert out.shape == (batch, cfg["K"], 2)
+        np.testing.assert_array_equal(out, want)                                    # every rank holds the full result
+        per = -(-batch // world)
+        assert cov.shape == (batch, cfg["K"], 2, 2) and cov[0, 0, 0, 0] == 0 and cov[per, 0, 0, 0] == 1000

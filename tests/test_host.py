@@ -1,0 +1,124 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/pvnet_vote.h declares, the
+pybind module keeps the reference's surface, the drop-in import path and signatures match the reference, and the
+product fails loudly (no CPU fallback) -- no compute call is made here."""
+import ctypes
+import inspect
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    names = capi.declared_symbols()
+    assert {"pvv_generate_hypothesis", "pvv_voting_for_hypothesis", "pvv_generate_hypothesis_vanishing_point",
+            "pvv_voting_for_hypothesis_vanishing_point", "pvv_count_inliers", "pvv_ransac_voting_v3",
+            "pvv_estimate_voting_distribution", "pvv_workspace_bytes", "pvv_default_cap", "pvv_last_error",
+            "pvv_abi_version", "pvv_rerun_count_kernel"} <= set(names)
+    L = ctypes.CDLL(capi.LIBPATH)
+    for n in names:
+        assert hasattr(L, n), "libpvnet_vote.so does not export %s" % n
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIBPATH]).decode()
+    exported = {l.split()[-1] for l in nm.splitlines() if " T " in l}
+    assert {e for e in exported if e.startswith("pvv_")} == set(names)     # nothing undeclared leaks out either
+
+
+def test_cabi_version_and_cap_and_validation():
+    L = capi.load()
+    assert L.pvv_abi_version() == 1
+    assert L.pvv_default_cap(480, 640, 30000) == 30000 + int(8 * 30000 ** 0.5) + 64
+    assert L.pvv_default_cap(128, 128, 30000) == 128 * 128
+    p = capi.Problem()
+    assert L.pvv_workspace_bytes(ctypes.byref(p)) == 0 and b"positive" in L.pvv_last_error()
+    p.B, p.H, p.W, p.K, p.hn, p.mask_elem_size, p.cap = 2, 480, 640, 9, 512, 8, 31449
+    n = L.pvv_workspace_bytes(ctypes.byref(p))
+    assert n > 2 * 9 * 31449 * (8 + 32)                       # dirs + records dominate
+    p.mask_elem_size = 3
+    assert L.pvv_workspace_bytes(ctypes.byref(p)) == 0 and b"mask_elem_size" in L.pvv_last_error()
+    p.mask_elem_size, p.B = 8, 5000
+    assert L.pvv_workspace_bytes(ctypes.byref(p)) == 0 and b"split the batch" in L.pvv_last_error()
+    # NULL pointers are rejected before any launch
+    p.B = 1
+    assert L.pvv_ransac_voting_v3(ctypes.byref(p), None, None, None, None, None, 0, None, None, None, None) == -1
+    assert L.pvv_generate_hypothesis(None, None, None, None, 1, 1, 1, None) == -1
+
+
+def test_extension_module_surface_matches_reference(pkg):
+    from clean_pvnet_amd import ransac_voting as ext
+    for name in ("generate_hypothesis", "voting_for_hypothesis", "generate_hypothesis_vanishing_point",
+                 "voting_for_hypothesis_vanishing_point"):                  # ransac_voting.cpp:102-107
+        assert callable(getattr(ext, name))
+    assert ext.abi_version == 1
+    import lib.csrc.ransac_voting.ransac_voting as ref_path                  # ransac_voting_gpu.py:2
+    assert ref_path.generate_hypothesis is ext.generate_hypothesis
+
+
+def test_drop_in_import_path_and_signatures(pkg):
+    from lib.csrc.ransac_voting.ransac_voting_gpu import (b_inv, estimate_voting_distribution_with_mean,   # resnet18.py:5
+                                                          ransac_voting_layer, ransac_voting_layer_v3)
+
+    def positional(f):
+        return [(p.name, p.default) for p in inspect.signature(f).parameters.values()
+                if p.kind == p.POSITIONAL_OR_KEYWORD]
+    E = inspect.Parameter.empty
+    v3 = [("mask", E), ("vertex", E), ("round_hyp_num", E), ("inlier_thresh", 0.999), ("confidence", 0.99),
+          ("max_iter", 20), ("min_num", 5), ("max_num", 30000)]                # ransac_voting_gpu.py:112-113
+    assert positional(ransac_voting_layer_v3) == v3
+    assert positional(ransac_voting_layer) == v3                                # :6-7
+    assert positional(estimate_voting_distribution_with_mean) == [
+        ("mask", E), ("vertex", E), ("mean", E), ("round_hyp_num", 256), ("min_hyp_num", 4096), ("topk", 128),
+        ("inlier_thresh", 0.99), ("min_num", 5), ("max_num", 30000), ("output_hyp", False)]   # :202
+    assert positional(b_inv) == [("b_mat", E)]
+
+
+def test_no_cpu_fallback(pkg):
+    from clean_pvnet_amd import ransac_voting as ext
+    from lib.csrc.ransac_voting.ransac_voting_gpu import estimate_voting_distribution_with_mean, ransac_voting_layer_v3
+    mask = torch.ones(1, 8, 8, dtype=torch.int64)
+    vertex = torch.zeros(1, 8, 8, 2, 2)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ransac_voting_layer_v3(mask, vertex, 16)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        estimate_voting_distribution_with_mean(mask, vertex, torch.zeros(1, 2, 2))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ext.voting_for_hypothesis(torch.zeros(4, 2, 2), torch.zeros(4, 2), torch.zeros(3, 2, 2),
+                                  torch.zeros(3, 2, 4, dtype=torch.uint8), 0.99)
+
+
+def test_missing_extension_fails_loudly(tmp_path):
+    """Copy the Python side without the .so files: importing the layers must raise, not fall back."""
+    import shutil
+    dst = tmp_path / "clean-pvnet_amd"
+    dst.mkdir()
+    for f in ("__init__.py", "ransac_voting_gpu.py"):
+        shutil.copy(os.path.join(ROOT, "clean-pvnet_amd", f), dst / f)
+    code = ("import importlib.util,sys;"
+            "spec=importlib.util.spec_from_file_location('clean_pvnet_amd', r'%s/__init__.py', submodule_search_locations=[r'%s']);"
+            "m=importlib.util.module_from_spec(spec);sys.modules['clean_pvnet_amd']=m;spec.loader.exec_module(m)" % (dst, dst))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr.replace("There is no CPU fallback", "no CPU fallback")
+
+
+def test_b_inv_reference_fallback_semantics(pkg):
+    from clean_pvnet_amd.ransac_voting_gpu import b_inv
+    good = torch.tensor([[[2., 0.], [0., 4.]], [[1., 1.], [0., 1.]]])
+    torch.testing.assert_close(b_inv(good) @ good, torch.eye(2).expand(2, 2, 2))
+    bad = good.clone()
+    bad[1] = torch.tensor([[1., 2.], [2., 4.]])                  # one singular member -> identity for the WHOLE batch
+    torch.testing.assert_close(b_inv(bad), torch.eye(2).expand(2, 2, 2))
+
+
+def test_shard_bounds_cover_batch_exactly(pkg):
+    from clean_pvnet_amd.dist import shard_bounds
+    for batch in (1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(batch, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == batch
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) == -(-batch // world)

@@ -1,0 +1,177 @@
+"""CPU tests of the oracle itself: C restatement vs numpy twin, vs the golden fixtures produced by the reference's
+own Python glue (tests/golden/make_golden.py), known-answer fields, and the edge cases of SURVEY.md appendix A.5."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return dict(np.load(os.path.join(GOLD, name + ".npz")))
+
+
+def _case(oracle, synth, cfg="cfg1", seed=1234, **over):
+    d = synth.make_batch(**{**synth.CONFIGS[cfg], **over, "B": 1}, seed=seed)
+    fg, coords, direct = oracle.compact_v3(d["mask"][0].numpy(), d["vertex"][0].numpy())
+    return d, coords, direct
+
+
+# ---------------------------------------------------------------------------------- kernels: C vs numpy twin
+@pytest.mark.parametrize("hn", [1, 37, 64])
+def test_generate_hypothesis_c_equals_numpy_twin(oracle, synth, hn):
+    d, coords, direct = _case(oracle, synth)
+    tn, vn, _ = direct.shape
+    idxs = np.random.RandomState(0).randint(0, tn, (hn, vn, 2)).astype(np.int32)
+    idxs[0, :, 1] = idxs[0, :, 0]
+    a = oracle.generate_hypothesis(direct, coords, idxs)
+    b = oracle.np_generate_hypothesis(direct, coords, idxs)
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert (a[0] == 0).all()                                   # t0 == t1 -> degenerate -> stays (0,0)
+
+
+@pytest.mark.parametrize("thresh", [0.99, 0.999])
+def test_voting_c_equals_numpy_twin_and_count(oracle, synth, thresh):
+    d, coords, direct = _case(oracle, synth)
+    tn, vn, _ = direct.shape
+    hn = 48
+    hyp = oracle.generate_hypothesis(direct, coords, np.random.RandomState(1).randint(0, tn, (hn, vn, 2)).astype(np.int32))
+    inl = oracle.voting_for_hypothesis(direct, coords, hyp, np.zeros((hn, vn, tn), np.uint8), thresh)
+    np.testing.assert_array_equal(inl.astype(bool), oracle.np_vote_mask(direct, coords, hyp, thresh))
+    np.testing.assert_array_equal(inl.sum(2), oracle.count_inliers(direct, coords, hyp, thresh))
+    assert inl.sum() > 0
+    pre = np.full((hn, vn, tn), 9, np.uint8)                   # kernel only ever writes 1
+    oracle.voting_for_hypothesis(direct, coords, hyp, pre, thresh)
+    np.testing.assert_array_equal(pre, np.where(inl == 1, 1, 9))
+
+
+def test_vote_guards_and_nonfinite(oracle):
+    """norm1 < 1e-6, norm2 < 1e-6 (hypothesis on the pixel), NaN / Inf directions: never inliers (A.2)."""
+    coords = np.array([[10, 10], [11, 10], [12, 10], [13, 10], [14, 10]], np.float32)
+    direct = np.array([[[1, 0]], [[0, 0]], [[np.nan, 1]], [[np.inf, 0]], [[9e-7, 0]]], np.float32)
+    hyp = np.array([[[20, 10]], [[10, 10]], [[10 + 5e-7, 10]]], np.float32)
+    c = oracle.count_inliers(direct, coords, hyp, 0.99)
+    assert c[:, 0].tolist() == [1, 0, 0]
+    np.testing.assert_array_equal(oracle.np_vote_mask(direct, coords, hyp, 0.99).sum(2), c)
+
+
+def test_vanishing_point_pair_runs_and_is_consistent(oracle, synth):
+    d, coords, direct = _case(oracle, synth)
+    tn, vn, _ = direct.shape
+    idxs = np.random.RandomState(2).randint(0, tn, (32, vn, 2)).astype(np.int32)
+    h = oracle.generate_hypothesis_vanishing_point(direct, coords, idxs)
+    assert h.shape == (32, vn, 3)
+    ok = np.abs(h[..., 2]) > 1e-3                              # finite intersections: h.xy / h.z is the 2-line intersection
+    e = oracle.generate_hypothesis(direct, coords, idxs)
+    good = ok & (np.abs(e).sum(-1) > 0)
+    with np.errstate(all="ignore"):
+        q = h[..., :2] / h[..., 2:3]
+    np.testing.assert_allclose(q[good], e[good], rtol=2e-3, atol=2e-2)
+    inl = oracle.voting_for_hypothesis_vanishing_point(direct, coords, h, np.zeros((32, vn, tn), np.uint8), 0.99)
+    assert inl.sum() > 0
+
+
+# ---------------------------------------------------------------------------------- glue vs the reference's own code
+def test_golden_v3_basic_matches_reference_glue(oracle):
+    c = gold("v3_basic")
+    det = []
+    out = oracle.ransac_voting_layer_v3(c["mask"], c["vertex"], int(c["hn"]), float(c["thresh"]), idxs=c["idxs"], details=det)
+    # reference accumulates the normal equations in binary32, the oracle in binary64: 1e-4 tolerance of north_star
+    np.testing.assert_allclose(out, c["out"], rtol=0, atol=2e-4)
+    assert (c["out"][2] == 0).all() and det[2]["skipped"]      # < min_num pixels -> zeros (:129-132)
+    assert np.abs(out[:2] - c["kpt"][:2]).max() < 1.5           # and it recovers the keypoints the field encodes
+    # the reference's confidence loop ran more than once for some image yet the output equals round 1 (A.3)
+    assert int(c["loop_calls"][0]) >= 2
+
+
+def test_golden_v3_subsample_matches_reference_glue(oracle):
+    c = gold("v3_subsample")
+    out = oracle.ransac_voting_layer_v3(c["mask"], c["vertex"], int(c["hn"]), float(c["thresh"]), idxs=c["idxs"],
+                                        selection=c["selection"], max_num=int(c["max_num"]))
+    np.testing.assert_allclose(out, c["out"], rtol=0, atol=5e-4)
+
+
+def test_golden_v3_singular_reference_policy(oracle):
+    """b_inv's whole-image identity fallback (:97-109): every keypoint of the image returns ATb."""
+    c = gold("v3_singular")
+    det = []
+    out = oracle.ransac_voting_layer_v3(c["mask"], c["vertex"], int(c["hn"]), float(c["thresh"]), idxs=c["idxs"], details=det)
+    assert det[0]["singular"].tolist() == [0, 0, 1, 0]
+    np.testing.assert_allclose(out, c["out"], rtol=2e-6, atol=1e-3)
+    assert np.abs(c["out"]).max() > 1e3                         # garbage by design: that IS the reference behaviour
+    z = oracle.ransac_voting_layer_v3(c["mask"], c["vertex"], int(c["hn"]), float(c["thresh"]), idxs=c["idxs"], singular="zero")
+    assert (z[0, 2] == 0).all() and np.abs(z[0, [0, 1, 3]] - c["kpt"][0, [0, 1, 3]]).max() < 1.5
+
+
+def test_golden_v1_layer(oracle):
+    c = gold("v1_basic")
+    out = oracle.ransac_voting_layer_v3(c["mask"], c["vertex"], int(c["hn"]), float(c["thresh"]), idxs=c["idxs"])
+    np.testing.assert_allclose(out, c["out"], rtol=0, atol=2e-4)
+
+
+def test_golden_estimate_matches_reference_glue(oracle):
+    c = gold("estimate_basic")
+    _m, cov = oracle.estimate_voting_distribution_with_mean(c["mask"], c["vertex"], c["mean"], int(c["round_hyp_num"]),
+                                                            int(c["min_hyp_num"]), idxs=c["idxs"])
+    np.testing.assert_allclose(cov, c["cov"], rtol=2e-5, atol=1e-4)
+    assert np.abs(c["cov"][1]).max() > 100                      # skipped image: hyps = 0, ratios = 1 -> mean mean^T
+
+
+# ---------------------------------------------------------------------------------- known answers / properties
+def test_known_answer_clean_field(oracle, synth):
+    """compute_vertex semantics (pvnet_data_utils.py:30-44) without noise: voting returns the keypoints."""
+    d = synth.make_batch(**{**synth.CONFIGS["cfg1"], "sigma": 0.0}, seed=3)
+    tn = [int(x) for x in (d["mask"] != 0).sum((1, 2))]
+    idxs = synth.make_idxs(tn, 64, 4, seed=3).numpy()
+    out = oracle.ransac_voting_layer_v3(d["mask"].numpy(), d["vertex"].numpy(), 64, 0.999, idxs=idxs)
+    np.testing.assert_allclose(out, d["kpt_2d"].numpy(), atol=2e-2)
+
+
+def test_permutation_of_batch_permutes_output(oracle, synth):
+    d = synth.make_batch(**{**synth.CONFIGS["cfg1"], "B": 3}, seed=4)
+    tn = [int(x) for x in (d["mask"] != 0).sum((1, 2))]
+    idxs = synth.make_idxs(tn, 64, 4, seed=4).numpy()
+    m, v = d["mask"].numpy(), d["vertex"].numpy()
+    a = oracle.ransac_voting_layer_v3(m, v, 64, 0.99, idxs=idxs)
+    p = [2, 0, 1]
+    b = oracle.ransac_voting_layer_v3(m[p], v[p], 64, 0.99, idxs=idxs[p])
+    np.testing.assert_array_equal(a[p], b)
+
+
+def test_mask_byte_semantics(oracle, synth):
+    """mask.byte() wraps modulo 256 and foreground_num is the SUM of the bytes (:125-126)."""
+    d = synth.make_batch(**synth.CONFIGS["cfg1"], seed=5)
+    m = d["mask"][0].numpy().copy()
+    v = d["vertex"][0].numpy()
+    fg1, c1, _ = oracle.compact_v3(m, v)
+    fg3, c3, _ = oracle.compact_v3(m * 3, v)
+    assert fg3 == 3 * fg1 and len(c3) == len(c1)
+    fg256, c256, _ = oracle.compact_v3(m * 256, v)             # int64 256 -> byte 0: empty
+    assert fg256 == 0 and len(c256) == 0
+    fge, ce, _ = oracle.compact_estimate(m * 3, v)             # estimate: `== 1` -> nothing
+    assert fge == 0
+
+
+def test_strided_planar_vertex_equals_contiguous(oracle, synth):
+    a = synth.make_batch(**synth.CONFIGS["cfg1"], seed=6)
+    b = synth.make_batch(**synth.CONFIGS["cfg1"], seed=6, planar=True)
+    assert not b["vertex"].is_contiguous()
+    np.testing.assert_array_equal(a["vertex"].numpy(), b["vertex"].numpy())
+    tn = [int(x) for x in (a["mask"] != 0).sum((1, 2))]
+    idxs = synth.make_idxs(tn, 64, 4, seed=6).numpy()
+    np.testing.assert_array_equal(oracle.ransac_voting_layer_v3(a["mask"].numpy(), a["vertex"].numpy(), 64, 0.99, idxs=idxs),
+                                  oracle.ransac_voting_layer_v3(b["mask"].numpy(), b["vertex"].numpy(), 64, 0.99, idxs=idxs))
+
+
+def test_argmax_takes_first_maximum(oracle):
+    """ties in torch.max(counts, 0): first index (A.3)."""
+    coords = np.array([[0, 0], [10, 0], [0, 10], [10, 10]], np.float32)
+    direct = np.zeros((4, 1, 2), np.float32)
+    tgt = np.array([5, 5], np.float32)
+    direct[:, 0] = (tgt - coords) / np.linalg.norm(tgt - coords, axis=1, keepdims=True)
+    idxs = np.array([[[0, 1]], [[2, 3]], [[0, 3]]], np.int32)          # third pair is collinear -> degenerate (0,0)
+    r = oracle.v3_image(direct, coords, idxs, 0.99)
+    # the degenerate (0,0) hypothesis is still voted on like any other (A.1): pixel (10,10) looks straight at it
+    assert (r["hypo_pts"][2, 0] == 0).all()
+    assert r["counts"][:, 0].tolist() == [4, 4, 1] and r["win_idx"][0] == 0
