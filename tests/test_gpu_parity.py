@@ -403,3 +403,100 @@ def test_stress_configs_sampled_oracle(oracle, synth, pkg, gpu, cfg, B):
                                               selection.to(gpu), 0, ext.SINGULAR_REFERENCE)
     assert _np(tnn).tolist() == tn
     _check_v3(oracle, out[:1], win[:1], tnn[:1], mask[:1], vertex[:1], idxs[:1], c["hn"], 0.99, selection=selection[:1])
+
+
+# --------------------------------------------------------------------------------------------------
+# shapes / thresholds / non-finite inputs
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,hn,thresh", [
+    (1, 64, 0.99),        # single keypoint
+    (17, 100, 0.99),      # hn not a multiple of 64 (R=2 tile with padded lanes)
+    (4, 130, 0.999),      # reference default threshold (kappa = 22.3), R=4
+    (4, 700, 0.99),       # two hypothesis tiles of 512, second one ragged
+    (3, 64, 0.3),         # threshold outside the fast path's range -> exact kernel
+    (3, 64, 0.99999),     # ditto, above
+])
+def test_v3_parity_shapes_and_thresholds(oracle, synth, pkg, gpu, K, hn, thresh):
+    from clean_pvnet_amd import ransac_voting as ext
+    c = {**synth.CONFIGS["cfg1"], "B": 2, "K": K}
+    d = synth.make_batch(**c, seed=31 + K)
+    mask, vertex = d["mask"], d["vertex"]
+    tn = [int(x) for x in (mask != 0).sum((1, 2))]
+    idxs = synth.make_idxs(tn, hn, K, seed=31 + K)
+    out, win, tnn, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), hn, thresh, 5, 30000, idxs.to(gpu), None, 0,
+                                              ext.SINGULAR_ZERO)
+    det = []
+    want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, thresh, idxs=_np(idxs), details=det, singular="zero")
+    np.testing.assert_array_equal(_np(win), np.stack([r["win_counts"] for r in det]))
+    np.testing.assert_allclose(_np(out), want, rtol=0, atol=ATOL)
+    # every one of the hn*K counts, not just the winners
+    m, v = mask.to(gpu), vertex.to(gpu)
+    mean = torch.zeros(2, K, 2, device=gpu)
+    if hn % 1 == 0:
+        cov, hyp, counts, tn2 = capi.estimate(m, v, mean, hn, thresh, idxs=idxs.to(gpu))
+        det2 = []
+        oracle.estimate_voting_distribution_with_mean(_np(mask), _np(vertex), _np(mean), hn, hn, inlier_thresh=thresh,
+                                                      idxs=_np(idxs), details=det2)
+        for bi in range(2):
+            np.testing.assert_array_equal(_np(counts[bi]), det2[bi]["counts"].T)
+
+
+def test_v3_nonfinite_and_degenerate_vertex_values(oracle, synth, pkg, gpu):
+    """NaN / Inf / zero / huge direction vectors on foreground pixels: hypotheses built from them are NaN, Inf
+    or astronomically far (exact-loop fallback of the fast kernel); counts must still be bit-exact."""
+    from clean_pvnet_amd import ransac_voting as ext
+    c = {**synth.CONFIGS["cfg1"], "B": 2}
+    d = synth.make_batch(**c, seed=41)
+    mask, vertex = d["mask"], d["vertex"]
+    ys, xs = np.nonzero(_np(mask[0]))
+    rng = np.random.RandomState(0)
+    pick = rng.choice(len(ys), 60, replace=False)
+    vals = [np.nan, np.inf, -np.inf, 0.0, 1e30, 1e-30, 3e19, 1e-7]
+    for j, pi in enumerate(pick):
+        vertex[0, ys[pi], xs[pi], j % 4, j % 2] = vals[j % len(vals)]
+    # two nearly parallel directions -> a hypothesis ~1e9 px away; exactly parallel -> degenerate (0,0)
+    ys1, xs1 = np.nonzero(_np(mask[1]))
+    vertex[1, ys1[0], xs1[0], 0] = torch.tensor([1.0, 0.0])
+    j = int(np.argmax(ys1 != ys1[0]))                                     # first pixel of the next row
+    vertex[1, ys1[j], xs1[j], 0] = torch.tensor([1.0, 2e-6])
+    tn = [int(x) for x in (mask != 0).sum((1, 2))]
+    hn = 256
+    idxs = synth.make_idxs(tn, hn, 4, seed=41)
+    idxs[0, :60, :, 0] = torch.from_numpy(np.searchsorted(np.flatnonzero(_np(mask[0]).ravel()),
+                                                          ys[pick] * mask.shape[2] + xs[pick]).astype(np.int32))[:, None]
+    idxs[1, 0, 0] = torch.tensor([0, j], dtype=torch.int32)               # the near-parallel pair
+    mean = torch.zeros(2, 4, 2)
+    det = []
+    with np.errstate(all="ignore"):
+        oracle.estimate_voting_distribution_with_mean(_np(mask), _np(vertex), _np(mean), hn, hn, idxs=_np(idxs), details=det)
+    cov, hyp, counts, tnn = capi.estimate(mask.to(gpu), vertex.to(gpu), mean.to(gpu), hn, 0.99, idxs=idxs.to(gpu))
+    for bi in range(2):
+        got_h, want_h = _np(hyp[bi]), det[bi]["hypo_pts"].transpose(1, 0, 2)
+        np.testing.assert_array_equal(got_h, want_h)                       # NaN == NaN here; x86 and gfx950 differ in the
+        fin = np.isfinite(want_h)                                          # default NaN's sign bit only
+        np.testing.assert_array_equal(got_h[fin].view(np.uint32), want_h[fin].view(np.uint32))
+        np.testing.assert_array_equal(_np(counts[bi]), det[bi]["counts"].T)
+    assert not np.isfinite(det[0]["hypo_pts"]).all()                        # the case really contains NaN/Inf hypotheses
+    assert np.abs(det[1]["hypo_pts"][np.isfinite(det[1]["hypo_pts"])]).max() > 1e5
+
+
+def test_estimate_subsample_and_multiclass(oracle, synth, pkg, gpu):
+    """estimate with foreground > max_num (fresh count after the subsample, P:219-223) and a mask holding classes
+    {0,1,2}: only `== 1` pixels vote."""
+    from clean_pvnet_amd.ransac_voting_gpu import estimate_voting_distribution_with_mean
+    c = {**synth.CONFIGS["cfg1"], "B": 2, "fg": 0.3}
+    d = synth.make_batch(**c, seed=51)
+    mask, vertex = d["mask"], d["vertex"]
+    mask[1, :, :64][mask[1, :, :64] != 0] = 2
+    max_num = 1000
+    selection = torch.rand(mask.shape, generator=torch.Generator().manual_seed(4))
+    fg = (mask == 1).sum((1, 2)).float()
+    kept = (mask == 1) & ((fg <= max_num).view(-1, 1, 1) | (selection < (torch.tensor(float(max_num)) / fg).view(-1, 1, 1)))
+    tn = [int(x) for x in kept.sum((1, 2))]
+    idxs = synth.make_idxs(tn, 128, 4, seed=51)
+    mean = d["kpt_2d"].clone()
+    _m, want = oracle.estimate_voting_distribution_with_mean(_np(mask), _np(vertex), _np(mean), 64, 128, max_num=max_num,
+                                                             idxs=_np(idxs), selection=_np(selection))
+    _m2, cov = estimate_voting_distribution_with_mean(mask.to(gpu), vertex.to(gpu), mean.to(gpu), 64, 128, max_num=max_num,
+                                                      idxs=idxs.to(gpu), selection=selection.to(gpu))
+    np.testing.assert_allclose(_np(cov), want, rtol=1e-4, atol=ATOL)
