@@ -179,21 +179,28 @@ __device__ __forceinline__ float selection_draw(const MaskArgs &a, int b, int p)
     return (float)(rng_u32(a.seed, 0u, (uint32_t)b, (uint32_t)p) >> 8) * 0x1p-24f;
 }
 
+// Pass 1 -- the ONLY pass that reads the mask: per tile of 2048 pixels the foreground count, the weight sum
+// (foreground_num of P:126 sums byte VALUES) and a 2048-bit foreground map (one wave64 ballot per 64 pixels,
+// word s*4+w = step s, wave w).  Later passes work from the bit map.
 template <int ES>
 __global__ __launch_bounds__(kBlock) void k_tile_count(MaskArgs a, int *__restrict__ tile_nz,
-                                                       int *__restrict__ tile_sum)
+                                                       int *__restrict__ tile_sum,
+                                                       unsigned long long *__restrict__ bits)
 {
     __shared__ int red[4];
     const int t = blockIdx.x, b = blockIdx.y;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    unsigned long long *wb = bits + ((size_t)b * a.T + t) * (kTileSteps * 4);
     int nz = 0, sum = 0;
 #pragma unroll
     for (int s = 0; s < kTileSteps; ++s) {
         int p = t * kTile + s * kBlock + threadIdx.x;
-        if (p < a.HW) {
-            int w = mask_weight<ES>(a, b, p);
-            nz += (w != 0);
-            sum += w;
-        }
+        int w = 0;
+        if (p < a.HW) w = mask_weight<ES>(a, b, p);
+        unsigned long long m = __ballot(w != 0);
+        if (lane == 0) wb[s * 4 + wave] = m;
+        nz += (w != 0);
+        sum += w;
     }
     nz = block_sum(nz, red);
     sum = block_sum(sum, red);
@@ -213,22 +220,29 @@ __device__ __forceinline__ long long image_fg(const int *__restrict__ tile_sum, 
 }
 
 // P:135-138 / P:219-223: when foreground_num > max_num every foreground pixel survives with
-// probability max_num/foreground_num (binary32 quotient).  Recount the survivors per tile.
-template <int ES>
-__global__ __launch_bounds__(kBlock) void k_tile_recount(MaskArgs a, int *__restrict__ tile_nz,
-                                                         const int *__restrict__ tile_sum)
+// probability max_num/foreground_num (binary32 quotient).  Clears the dropped pixels in the bit map and
+// recounts the tile.  Images that are not subsampled exit at once.
+__global__ __launch_bounds__(kBlock) void k_tile_subsample(MaskArgs a, int *__restrict__ tile_nz,
+                                                           const int *__restrict__ tile_sum,
+                                                           unsigned long long *__restrict__ bits)
 {
     __shared__ long long redl[4];
     __shared__ int red[4];
     const int t = blockIdx.x, b = blockIdx.y;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
     long long fg = image_fg(tile_sum, b, a.T, redl);
     if (fg <= (long long)a.max_num) return;
     const float prob = (float)a.max_num / (float)fg;
+    unsigned long long *wb = bits + ((size_t)b * a.T + t) * (kTileSteps * 4);
     int nz = 0;
 #pragma unroll
     for (int s = 0; s < kTileSteps; ++s) {
         int p = t * kTile + s * kBlock + threadIdx.x;
-        if (p < a.HW && mask_weight<ES>(a, b, p) != 0 && selection_draw(a, b, p) < prob) ++nz;
+        bool f = (wb[s * 4 + wave] >> lane) & 1ull;
+        if (f) f = selection_draw(a, b, p) < prob;
+        unsigned long long m = __ballot(f);
+        if (lane == 0) wb[s * 4 + wave] = m;
+        nz += f ? 1 : 0;
     }
     nz = block_sum(nz, red);
     if (threadIdx.x == 0) tile_nz[b * a.T + t] = nz;
@@ -273,10 +287,10 @@ __device__ __forceinline__ PixelRec make_record(float cx, float cy, float nx, fl
 // Ordered scatter: pixel -> row r of the image's compacted list; writes coords[b][r] = (x,y)
 // (P:140-141) and dirs[b][vi][r] = vertex[b,y,x,vi,:] (P:142-143, stored planar per keypoint so
 // that the count kernel's loads are unit-stride).
-template <int ES>
 __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
                                                     const int *__restrict__ tile_nz,
                                                     const int *__restrict__ tile_sum,
+                                                    const unsigned long long *__restrict__ bits,
                                                     int *__restrict__ tn_out,
                                                     float2 *__restrict__ coords,
                                                     float2 *__restrict__ dirs,
@@ -288,13 +302,13 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
     const int t = blockIdx.x, b = blockIdx.y;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
 
+    if (t != 0 && tile_nz[b * a.T + t] == 0) return;  // background-only tile: nothing to scatter
+
     const long long fg = image_fg(tile_sum, b, a.T, redl);
     if (fg < (long long)a.min_num) {  // P:129-132 / P:211-216: image skipped
         if (t == 0 && threadIdx.x == 0) tn_out[b] = 0;
         return;
     }
-    const bool subsample = fg > (long long)a.max_num;
-    const float prob = subsample ? (float)a.max_num / (float)fg : 2.0f;
 
     int before = 0, total = 0;
     for (int i = threadIdx.x; i < a.T; i += kBlock) {
@@ -306,18 +320,12 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
     total = block_sum(total, red);
     if (t == 0 && threadIdx.x == 0) tn_out[b] = total < a.cap ? total : a.cap;
 
-    unsigned keep = 0;
+    const unsigned long long *wb = bits + ((size_t)b * a.T + t) * (kTileSteps * 4);
+    unsigned long long word[kTileSteps];
 #pragma unroll
     for (int s = 0; s < kTileSteps; ++s) {
-        int p = t * kTile + s * kBlock + threadIdx.x;
-        bool f = false;
-        if (p < a.HW) {
-            f = mask_weight<ES>(a, b, p) != 0;
-            if (f && subsample) f = selection_draw(a, b, p) < prob;
-        }
-        unsigned long long m = __ballot(f);
-        if (lane == 0) seg[s * 4 + wave] = __popcll(m);
-        if (f) keep |= 1u << s;
+        word[s] = wb[s * 4 + wave];                       // wave-uniform
+        if (lane == 0) seg[s * 4 + wave] = __popcll(word[s]);
     }
     __syncthreads();
     if (threadIdx.x < 64) {  // wave 0: exclusive scan of the 32 (step,wave) segment counts
@@ -334,9 +342,8 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
 
 #pragma unroll
     for (int s = 0; s < kTileSteps; ++s) {
-        bool f = (keep >> s) & 1u;
-        unsigned long long m = __ballot(f);
-        if (!f) continue;
+        const unsigned long long m = word[s];
+        if (!((m >> lane) & 1ull)) continue;
         int r = before + seg[s * 4 + wave] + __popcll(m & ((1ull << lane) - 1ull));
         if (r >= a.cap) continue;
         int p = t * kTile + s * kBlock + threadIdx.x;
@@ -1004,7 +1011,7 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
     int T;
-    size_t tile_nz, tile_sum, tn, coords, dirs, recs, hyps, counts, sums, singular, pts, total;
+    size_t tile_nz, tile_sum, bits, tn, coords, dirs, recs, hyps, counts, sums, singular, pts, total;
 };
 
 Layout make_layout(const pvv_problem *p)
@@ -1016,6 +1023,7 @@ Layout make_layout(const pvv_problem *p)
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     L.tile_nz = take(sizeof(int) * (size_t)p->B * L.T);
     L.tile_sum = take(sizeof(int) * (size_t)p->B * L.T);
+    L.bits = take(sizeof(unsigned long long) * (size_t)p->B * L.T * kTileSteps * 4);
     L.tn = take(sizeof(int) * (size_t)p->B);
     L.coords = take(sizeof(float2) * (size_t)p->B * p->cap);
     L.dirs = take(sizeof(float2) * (size_t)p->B * p->K * p->cap);
@@ -1167,12 +1175,13 @@ int launch_compaction(const MaskArgs &m, const VertexArgs &v, const Layout &L, c
 {
     dim3 grid(L.T, B), block(kBlock);
     int *tile_nz = (int *)(ws + L.tile_nz), *tile_sum = (int *)(ws + L.tile_sum);
-    hipLaunchKernelGGL(k_tile_count<ES>, grid, block, 0, st, m, tile_nz, tile_sum);
+    unsigned long long *bits = (unsigned long long *)(ws + L.bits);
+    hipLaunchKernelGGL(k_tile_count<ES>, grid, block, 0, st, m, tile_nz, tile_sum, bits);
     if (int e = check_launch("k_tile_count")) return e;
-    hipLaunchKernelGGL(k_tile_recount<ES>, grid, block, 0, st, m, tile_nz, (const int *)tile_sum);
-    if (int e = check_launch("k_tile_recount")) return e;
-    hipLaunchKernelGGL(k_compact<ES>, grid, block, 0, st, m, v, (const int *)tile_nz,
-                       (const int *)tile_sum, (int *)(ws + L.tn), (float2 *)(ws + L.coords),
+    hipLaunchKernelGGL(k_tile_subsample, grid, block, 0, st, m, tile_nz, (const int *)tile_sum, bits);
+    if (int e = check_launch("k_tile_subsample")) return e;
+    hipLaunchKernelGGL(k_compact, grid, block, 0, st, m, v, (const int *)tile_nz, (const int *)tile_sum,
+                       (const unsigned long long *)bits, (int *)(ws + L.tn), (float2 *)(ws + L.coords),
                        (float2 *)(ws + L.dirs), (PixelRec *)(ws + L.recs));
     return check_launch("k_compact");
 }
