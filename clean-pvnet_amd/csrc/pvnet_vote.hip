@@ -13,6 +13,7 @@
 //   P = lib/csrc/ransac_voting/ransac_voting_gpu.py
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -737,6 +738,7 @@ __global__ __launch_bounds__(kBlock) void k_count_fast(
     }
 }
 
+
 // ---------------------------------------------------------------------------------------------
 // Stage 4 (v3): winner selection + least-squares refit (P:159-167 and P:176-196).
 // One block per (keypoint, image).
@@ -1085,6 +1087,7 @@ int launch_count(const CountArgs &a, hipStream_t st)
 
 // The fast test needs 0 < T < 1 with a sane kappa; outside [0.5, 0.99995] (and when PVV_COUNT_KERNEL=exact
 // is set, for A/B runs) the exact kernel is used.
+// PVV_COUNT_KERNEL=exact forces the sqrt/divide kernel (A/B runs; the tests exercise both).
 bool use_fast_count(float thresh)
 {
     static int forced = -1;
@@ -1152,6 +1155,8 @@ int launch_count_fast(const pvv_problem *p, const Layout &L, char *ws, hipStream
     return check_launch("k_count_fast");
 }
 
+int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st);
+
 CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
 {
     CountArgs a;
@@ -1167,6 +1172,12 @@ CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
     a.B = p->B; a.K = p->K; a.hn = p->hn;
     a.thresh = p->inlier_thresh;
     return a;
+}
+
+int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st)
+{
+    if (use_fast_count(p->inlier_thresh)) return launch_count_fast(p, L, ws, st);
+    return launch_count(planar_count_args(p, L, ws), st);
 }
 
 template <int ES>
@@ -1224,8 +1235,7 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
                        (const float2 *)(ws + L.dirs), (float2 *)(ws + L.hyps), (int *)(ws + L.counts),
                        p->B, p->K, p->hn, p->cap, p->seed);
     if ((e = check_launch("k_gen_hypothesis"))) return e;
-    if (use_fast_count(p->inlier_thresh)) return launch_count_fast(p, L, ws, st);
-    return launch_count(planar_count_args(p, L, ws), st);
+    return launch_count_any(p, L, ws, st);
 }
 
 int check_ptrs(const pvv_problem *p, const void *mask, const void *vertex, void *ws, size_t ws_bytes,
@@ -1330,8 +1340,7 @@ PVV_EXPORT int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace, s
         hipError_t e = hipMemsetAsync(ws + L.counts, 0, sizeof(int) * (size_t)p->B * p->K * p->hn, st);
         if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     }
-    if (use_fast_count(p->inlier_thresh)) return launch_count_fast(p, L, ws, st);
-    return launch_count(planar_count_args(p, L, ws), st);
+    return launch_count_any(p, L, ws, st);
 }
 
 // ---- legacy module surface ---------------------------------------------------------------
