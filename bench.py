@@ -162,6 +162,31 @@ def main():
                 estimate_voting_distribution_with_mean(mask, vertex, mean)
             torch.cuda.synchronize()
             extra["v3_plus_estimate_images_per_s"] = round(B * n2 / (time.perf_counter() - t2), 1)
+            # decode_keypoint with torch.argmax + v3 vs the argmax fused into the mask scan
+            from clean_pvnet_amd.decode import decode_keypoint
+            x = torch.randn(B, 2 + 2 * K, H, W, device=dev) * 0.1
+            x[:, 1] += 3.0 * (mask != 0)
+            x[:, 2:] = vertex.permute(0, 3, 4, 1, 2).reshape(B, 2 * K, H, W)
+            seg, ver = x[:, :2], x[:, 2:]
+
+            def unfused():
+                vtx = ver.permute(0, 2, 3, 1).view(B, H, W, K, 2)
+                m = torch.argmax(seg, 1)
+                return ransac_voting_layer_v3(m, vtx, hn, inlier_thresh=thresh, max_num=30000)
+
+            def fused():
+                return ext.decode_keypoint_v3(seg, ver.permute(0, 2, 3, 1).view(B, H, W, K, 2), hn, thresh, 5, 30000,
+                                              None, None, 7, ext.SINGULAR_REFERENCE)[0]
+            for name, fn in (("decode_unfused_images_per_s", unfused), ("decode_fused_images_per_s", fused)):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for _ in range(20):
+                    fn()
+                torch.cuda.synchronize()
+                extra[name] = round(B * 20 / (time.perf_counter() - t3), 1)
+            del decode_keypoint
 
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:

@@ -144,6 +144,11 @@ struct MaskArgs {
     int W, HW, T;
     int min_num, max_num, cap;
     uint64_t seed;
+    // fused argmax (decode_keypoint): when seg != nullptr the mask value is argmax_c seg[b,c,y,x]
+    const float *seg;
+    long long *mask_out;     // [B,H,W] int64 or nullptr
+    int64_t gb, gc, gh, gw;  // element strides of seg
+    int C;
 };
 
 template <int ES>
@@ -157,9 +162,29 @@ __device__ __forceinline__ uint64_t load_elem(const void *base, int64_t off)
 
 // weight of pixel p of image b: 0 = background; v3: low byte (P:125-126 sums the bytes),
 // estimate: 1 (P:207-208).
+// torch.argmax over the class axis: first maximal index, a NaN beats everything (and the first NaN wins)
+__device__ __forceinline__ int argmax_class(const MaskArgs &a, int b, int p)
+{
+    const int y = p / a.W;
+    const int x = p - y * a.W;
+    const float *q = a.seg + (int64_t)b * a.gb + (int64_t)y * a.gh + (int64_t)x * a.gw;
+    float best = q[0];
+    int idx = 0;
+    for (int c = 1; c < a.C; ++c) {
+        const float v = q[(int64_t)c * a.gc];
+        if (v > best || (v != v && best == best)) { best = v; idx = c; }
+    }
+    return idx;
+}
+
 template <int ES>
 __device__ __forceinline__ int mask_weight(const MaskArgs &a, int b, int p)
 {
+    if (a.seg) {
+        const int idx = argmax_class(a, b, p);
+        if (a.mask_out) a.mask_out[(int64_t)b * a.HW + p] = idx;
+        return a.mode == 0 ? (idx & 0xFF) : (idx == 1 ? 1 : 0);
+    }
     int64_t off;
     if (a.contig) {
         off = (int64_t)b * a.sb + p;
@@ -300,6 +325,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
     __shared__ long long redl[4];
     __shared__ int red[4];
     __shared__ int seg[kTileSteps * 4 + 1];
+    __shared__ unsigned short list[kTile];
     const int t = blockIdx.x, b = blockIdx.y;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
 
@@ -341,29 +367,45 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
     }
     __syncthreads();
 
+    // foreground pixels of the tile -> LDS list (in rank order), so that the K-fold gather below is spread over
+    // all 256 threads instead of looping inside the few lanes that own a foreground pixel
+    int nfg = 0;
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s) nfg += __popcll(word[s]);      // this wave's pixels ...
+    __syncthreads();
 #pragma unroll
     for (int s = 0; s < kTileSteps; ++s) {
         const unsigned long long m = word[s];
         if (!((m >> lane) & 1ull)) continue;
-        int r = before + seg[s * 4 + wave] + __popcll(m & ((1ull << lane) - 1ull));
-        if (r >= a.cap) continue;
-        int p = t * kTile + s * kBlock + threadIdx.x;
-        int y = p / a.W;
-        int x = p - y * a.W;
-        coords[(size_t)b * a.cap + r] = make_float2((float)x, (float)y);
-        const float *src = v.vertex + (int64_t)b * v.sb + (int64_t)y * v.sh + (int64_t)x * v.sw;
-        for (int vi = 0; vi < v.K; ++vi) {
-            float2 d;
-            if (v.vec2) {
-                d = *(const float2 *)(src + (int64_t)vi * v.sk);
-            } else {
-                d.x = src[(int64_t)vi * v.sk];
-                d.y = src[(int64_t)vi * v.sk + v.sc];
-            }
-            dirs[((size_t)b * v.K + vi) * a.cap + r] = d;
-            if (v.kappa != 0.0)
-                recs[((size_t)b * v.K + vi) * a.cap + r] = make_record((float)x, (float)y, d.x, d.y, v.kappa);
+        const int lr = seg[s * 4 + wave] + __popcll(m & ((1ull << lane) - 1ull));   // rank within the tile
+        list[lr] = (unsigned short)(s * kBlock + threadIdx.x);
+    }
+    __syncthreads();
+    const int tile_n = tile_nz[b * a.T + t];
+    const int room = a.cap - before;                                     // rows left in the image's list
+    const int n = tile_n < room ? tile_n : (room > 0 ? room : 0);
+    (void)nfg;
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        const int p = t * kTile + list[i];
+        const int y = p / a.W;
+        coords[(size_t)b * a.cap + before + i] = make_float2((float)(p - y * a.W), (float)y);
+    }
+    for (int i = threadIdx.x; i < n * v.K; i += kBlock) {
+        const int vi = i / n, li = i - vi * n;                           // consecutive threads -> consecutive rows
+        const int p = t * kTile + list[li];
+        const int y = p / a.W;
+        const int x = p - y * a.W;
+        const float *src = v.vertex + (int64_t)b * v.sb + (int64_t)y * v.sh + (int64_t)x * v.sw + (int64_t)vi * v.sk;
+        float2 d;
+        if (v.vec2) {
+            d = *(const float2 *)src;
+        } else {
+            d.x = src[0];
+            d.y = src[v.sc];
         }
+        const size_t row = ((size_t)b * v.K + vi) * a.cap + before + li;
+        dirs[row] = d;
+        if (v.kappa != 0.0) recs[row] = make_record((float)x, (float)y, d.x, d.y, v.kappa);
     }
 }
 
@@ -1200,10 +1242,14 @@ int launch_compaction(const MaskArgs &m, const VertexArgs &v, const Layout &L, c
 // compaction + hypotheses + counting, shared by both layers
 int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d_vertex,
               const int32_t *d_idxs, const float *d_selection, char *ws, const Layout &L,
-              hipStream_t st)
+              hipStream_t st, const float *d_seg = nullptr, int64_t *d_mask_out = nullptr)
 {
     MaskArgs m;
     m.mask = d_mask;
+    m.seg = d_seg;
+    m.mask_out = (long long *)d_mask_out;
+    m.gb = p->seg_stride[0]; m.gc = p->seg_stride[1]; m.gh = p->seg_stride[2]; m.gw = p->seg_stride[3];
+    m.C = p->seg_classes;
     m.selection = d_selection;
     m.sb = p->mask_stride[0]; m.sh = p->mask_stride[1]; m.sw = p->mask_stride[2];
     m.es = p->mask_elem_size;
@@ -1270,18 +1316,9 @@ PVV_EXPORT size_t pvv_workspace_bytes(const pvv_problem *p)
     return make_layout(p).total;
 }
 
-PVV_EXPORT int pvv_ransac_voting_v3(const pvv_problem *p, const void *d_mask, const float *d_vertex,
-                                    const int32_t *d_idxs, const float *d_selection,
-                                    void *d_workspace, size_t workspace_bytes, float *d_out,
-                                    int32_t *d_win_counts, int32_t *d_tn, void *stream)
+static int finish_v3(const pvv_problem *p, const Layout &L, char *ws, float *d_out, int32_t *d_win_counts,
+                     int32_t *d_tn, hipStream_t st)
 {
-    Layout L;
-    if (int e = check_ptrs(p, d_mask, d_vertex, d_workspace, workspace_bytes, &L)) return e;
-    if (!d_out) return fail(PVV_E_ARG, "d_out is NULL");
-    hipStream_t st = (hipStream_t)stream;
-    char *ws = (char *)d_workspace;
-    if (int e = run_front(p, 0, d_mask, d_vertex, d_idxs, d_selection, ws, L, st)) return e;
-
     hipLaunchKernelGGL(k_select_refit, dim3(p->K, p->B), dim3(kBlock), 0, st,
                        (const int *)(ws + L.tn), (const float2 *)(ws + L.coords),
                        (const float2 *)(ws + L.dirs), (const float2 *)(ws + L.hyps),
@@ -1300,6 +1337,36 @@ PVV_EXPORT int pvv_ransac_voting_v3(const pvv_problem *p, const void *d_mask, co
         if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     }
     return PVV_OK;
+}
+
+PVV_EXPORT int pvv_ransac_voting_v3(const pvv_problem *p, const void *d_mask, const float *d_vertex,
+                                    const int32_t *d_idxs, const float *d_selection,
+                                    void *d_workspace, size_t workspace_bytes, float *d_out,
+                                    int32_t *d_win_counts, int32_t *d_tn, void *stream)
+{
+    Layout L;
+    if (int e = check_ptrs(p, d_mask, d_vertex, d_workspace, workspace_bytes, &L)) return e;
+    if (!d_out) return fail(PVV_E_ARG, "d_out is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)d_workspace;
+    if (int e = run_front(p, 0, d_mask, d_vertex, d_idxs, d_selection, ws, L, st)) return e;
+    return finish_v3(p, L, ws, d_out, d_win_counts, d_tn, st);
+}
+
+PVV_EXPORT int pvv_decode_keypoint_v3(const pvv_problem *p, const float *d_seg, const float *d_vertex,
+                                      const int32_t *d_idxs, const float *d_selection, void *d_workspace,
+                                      size_t workspace_bytes, int64_t *d_mask_out, float *d_out,
+                                      int32_t *d_win_counts, int32_t *d_tn, void *stream)
+{
+    Layout L;
+    if (p && p->mask_elem_size == 0) return fail(PVV_E_ARG, "set mask_elem_size = 8 (the int64 mask this call emits)");
+    if (int e = check_ptrs(p, d_seg, d_vertex, d_workspace, workspace_bytes, &L)) return e;
+    if (!d_out) return fail(PVV_E_ARG, "d_out is NULL");
+    if (p->seg_classes < 1 || p->seg_classes > 256) return fail(PVV_E_ARG, "seg_classes must be in [1, 256]");
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)d_workspace;
+    if (int e = run_front(p, 0, nullptr, d_vertex, d_idxs, d_selection, ws, L, st, d_seg, d_mask_out)) return e;
+    return finish_v3(p, L, ws, d_out, d_win_counts, d_tn, st);
 }
 
 PVV_EXPORT int pvv_estimate_voting_distribution(const pvv_problem *p, const void *d_mask,

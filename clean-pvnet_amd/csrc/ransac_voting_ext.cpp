@@ -242,6 +242,34 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> ransac_voting_v3(
     return {out, win, tn, ws};
 }
 
+// Resnet18.decode_keypoint's front half fused: mask = argmax(seg, 1) + ransac_voting_layer_v3(mask, vertex, ...)
+// -> (kpt [b,vn,2], mask [b,h,w] int64, win_counts [b,vn], tn [b])
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_v3(
+    at::Tensor seg, at::Tensor vertex, int64_t round_hyp_num, double inlier_thresh, int64_t min_num, int64_t max_num,
+    std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection, int64_t seed, int64_t singular_policy)
+{
+    TORCH_CHECK(seg.is_cuda(), "seg must be a CUDA tensor");
+    TORCH_CHECK(seg.scalar_type() == at::kFloat, "seg must be float32, got ", seg.scalar_type());
+    TORCH_CHECK(seg.dim() == 4 && vertex.dim() == 5 && seg.size(0) == vertex.size(0) && seg.size(2) == vertex.size(1) &&
+                    seg.size(3) == vertex.size(2),
+                "seg must be [b,c,h,w] matching vertex [b,h,w,vn,2]");
+    auto mask = at::empty({seg.size(0), seg.size(2), seg.size(3)}, seg.options().dtype(at::kLong));
+    pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, singular_policy, seed);
+    p.seg_classes = (int32_t)seg.size(1);
+    for (int i = 0; i < 4; ++i) p.seg_stride[i] = seg.stride(i);
+    const int32_t *ip = opt_idxs(idxs, vertex, p);
+    const float *sp = opt_selection(selection, vertex, p);
+    at::Tensor ws = make_workspace(p, vertex);
+    auto out = at::empty({p.B, p.K, 2}, vertex.options());
+    auto win = at::empty({p.B, p.K}, vertex.options().dtype(at::kInt));
+    auto tn = at::empty({p.B}, vertex.options().dtype(at::kInt));
+    ok(pvv_decode_keypoint_v3(&p, seg.data_ptr<float>(), vertex.data_ptr<float>(), ip, sp, ws.data_ptr(),
+                              (size_t)ws.numel(), mask.data_ptr<int64_t>(), out.data_ptr<float>(),
+                              win.data_ptr<int32_t>(), tn.data_ptr<int32_t>(), cur_stream(vertex)),
+       "decode_keypoint_v3");
+    return {out, mask, win, tn};
+}
+
 // estimate_voting_distribution_with_mean for the whole batch
 // -> (cov [b,vn,2,2], hyp [b,vn,hn,2] | empty, counts [b,vn,hn] | empty, tn [b])
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> estimate_voting_distribution(
@@ -301,6 +329,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     // fused / batched additions
     m.def("count_inliers", &count_inliers, "fused vote + count -> [hn,vn] int32");
     m.def("ransac_voting_v3", &ransac_voting_v3, "batched ransac_voting_layer_v3");
+    m.def("decode_keypoint_v3", &decode_keypoint_v3, "argmax(seg) fused with batched ransac_voting_layer_v3");
     m.def("estimate_voting_distribution", &estimate_voting_distribution,
           "batched estimate_voting_distribution_with_mean");
     m.def("rerun_count_kernel", &rerun_count_kernel, "re-launch the inlier-count kernel (profiling aid)");

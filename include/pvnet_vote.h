@@ -30,7 +30,7 @@ extern "C" {
 #define PVV_E_WORKSPACE (-2) /* workspace smaller than pvv_workspace_bytes() */
 
 /* ABI version of this header; pvv_abi_version() must return the same. */
-#define PVV_ABI_VERSION 1
+#define PVV_ABI_VERSION 2
 
 int pvv_abi_version(void);
 const char *pvv_last_error(void);
@@ -99,6 +99,11 @@ typedef struct pvv_problem {
                                 e.g. the planar permute of resnet18.py:66-68)  */
     uint64_t seed;           /* counter-based RNG key, used when d_idxs /
                                 d_selection are NULL                           */
+    /* pvv_decode_keypoint_v3 only (ignored elsewhere): the segmentation logits */
+    int32_t seg_classes;     /* C of seg [B,C,H,W] (2 for PVNet, config.py:108-112) */
+    int32_t reserved_;
+    int64_t seg_stride[4];   /* element strides of seg [B,C,H,W] (a channel slice
+                                of the network output, resnet18.py:93)          */
 } pvv_problem;
 
 /* b_inv (P:97-109) falls back to the identity for the WHOLE image when the
@@ -133,6 +138,21 @@ int pvv_ransac_voting_v3(const pvv_problem *p, const void *d_mask,
                          const float *d_selection, void *d_workspace,
                          size_t workspace_bytes, float *d_out,
                          int32_t *d_win_counts, int32_t *d_tn, void *stream);
+
+/* Resnet18.decode_keypoint (lib/networks/pvnet/resnet18.py:65-76) with the
+ * argmax fused into the mask scan: mask = argmax(seg, 1) (first maximum; a NaN
+ * logit wins, as torch.argmax) is computed while the foreground is counted, so
+ * the int64 mask is written once and never read back.
+ *   d_seg       [B,C,H,W] f32 class logits through p->seg_stride
+ *   d_mask_out  [B,H,W] i64, contiguous: the `mask` entry of the output dict
+ *               (resnet18.py:72,76); may be NULL when the caller does not need it
+ * everything else as pvv_ransac_voting_v3 (foreground = class != 0). */
+int pvv_decode_keypoint_v3(const pvv_problem *p, const float *d_seg,
+                           const float *d_vertex, const int32_t *d_idxs,
+                           const float *d_selection, void *d_workspace,
+                           size_t workspace_bytes, int64_t *d_mask_out,
+                           float *d_out, int32_t *d_win_counts, int32_t *d_tn,
+                           void *stream);
 
 /* estimate_voting_distribution_with_mean (P:202-274); p->hn is the TOTAL
  * number of hypotheses (round_num * round_hyp_num, P:231-249).

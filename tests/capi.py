@@ -17,7 +17,8 @@ class Problem(ctypes.Structure):
     _fields_ = [("B", c_i32), ("H", c_i32), ("W", c_i32), ("K", c_i32), ("hn", c_i32),
                 ("mask_elem_size", c_i32), ("min_num", c_i32), ("max_num", c_i32), ("cap", c_i32),
                 ("singular_policy", c_i32), ("inlier_thresh", c_f32),
-                ("mask_stride", c_i64 * 3), ("vertex_stride", c_i64 * 5), ("seed", c_u64)]
+                ("mask_stride", c_i64 * 3), ("vertex_stride", c_i64 * 5), ("seed", c_u64),
+                ("seg_classes", c_i32), ("reserved_", c_i32), ("seg_stride", c_i64 * 4)]
 
 
 def declared_symbols():
@@ -46,6 +47,7 @@ def load():
         L.pvv_voting_for_hypothesis_vanishing_point.argtypes = legacy + [c_f32, vp]
         L.pvv_count_inliers.argtypes = legacy + [c_f32, vp]
         L.pvv_ransac_voting_v3.argtypes = [ctypes.POINTER(Problem), vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]
+        L.pvv_decode_keypoint_v3.argtypes = [ctypes.POINTER(Problem), vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]
         L.pvv_estimate_voting_distribution.argtypes = [ctypes.POINTER(Problem), vp, vp, vp, vp, vp, vp, sz,
                                                        vp, vp, vp, vp, vp]
         L.pvv_rerun_count_kernel.argtypes = [ctypes.POINTER(Problem), vp, sz, ctypes.c_int, vp]

@@ -500,3 +500,52 @@ def test_estimate_subsample_and_multiclass(oracle, synth, pkg, gpu):
     _m2, cov = estimate_voting_distribution_with_mean(mask.to(gpu), vertex.to(gpu), mean.to(gpu), 64, 128, max_num=max_num,
                                                       idxs=idxs.to(gpu), selection=selection.to(gpu))
     np.testing.assert_allclose(_np(cov), want, rtol=1e-4, atol=ATOL)
+
+
+# --------------------------------------------------------------------------------------------------
+# decode_keypoint (resnet18.py:65-76): argmax fused into the mask scan
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C", [2, 3])
+def test_decode_keypoint_fused_argmax_equals_unfused(oracle, synth, pkg, gpu, C):
+    from clean_pvnet_amd import ransac_voting as ext
+    from clean_pvnet_amd.decode import decode_keypoint
+    c = {**synth.CONFIGS["cfg1"], "B": 3, "K": 9}
+    d = synth.make_batch(**c, seed=61, planar=True)
+    B, H, W, K = 3, c["H"], c["W"], 9
+    # one network output tensor [B, C + 2K, H, W]; seg / vertex are channel slices of it (resnet18.py:93-94)
+    x = torch.empty(B, C + 2 * K, H, W)
+    g = torch.Generator().manual_seed(1)
+    x[:, :C] = torch.randn(B, C, H, W, generator=g) * 0.1
+    fg = d["mask"] != 0
+    x[:, 1][fg] += 3.0                                              # class 1 wins on the object
+    if C == 3:
+        x[:, 2, :, : W // 4][fg[:, :, : W // 4]] += 6.0             # class 2 wins on its left quarter
+    x[0, 0, 5, 7] = float("nan")                                    # NaN logit: torch.argmax returns its index
+    x[1, 1, 6, 8] = float("nan")
+    x[2, :C, 9, 9] = 1.25                                           # tie -> first index
+    x[:, C:] = d["vertex"].permute(0, 3, 4, 1, 2).reshape(B, 2 * K, H, W)
+    x = x.to(gpu)
+    seg, ver = x[:, :C], x[:, C:]
+    mask_ref = torch.argmax(seg, 1)
+    vertex = ver.permute(0, 2, 3, 1).view(B, H, W, K, 2)
+    tn = [int(v) for v in ((mask_ref & 0xFF) != 0).sum((1, 2)).cpu()]
+    hn = 128
+    idxs = synth.make_idxs(tn, hn, K, seed=61).to(gpu)
+    out_ref, win_ref, tn_ref, _ws = ext.ransac_voting_v3(mask_ref, vertex, hn, 0.99, 5, 30000, idxs, None, 0, ext.SINGULAR_REFERENCE)
+    out, mask, win, tnn = ext.decode_keypoint_v3(seg, vertex, hn, 0.99, 5, 30000, idxs, None, 0, ext.SINGULAR_REFERENCE)
+    assert mask.dtype == torch.int64
+    np.testing.assert_array_equal(_np(mask), _np(mask_ref))
+    assert int(mask_ref[0, 5, 7]) == 0 and int(mask_ref[1, 6, 8]) == 1 and int(mask_ref[2, 9, 9]) == 0
+    np.testing.assert_array_equal(_np(tnn), _np(tn_ref))
+    np.testing.assert_array_equal(_np(win), _np(win_ref))
+    np.testing.assert_array_equal(_np(out), _np(out_ref))           # same kernels downstream: bit-identical
+    want = oracle.ransac_voting_layer_v3(_np(mask_ref), _np(vertex), hn, 0.99, idxs=_np(idxs))
+    np.testing.assert_allclose(_np(out), want, rtol=0, atol=ATOL)
+    # the dict-updating mirror of the reference method, both branches
+    o = decode_keypoint({"seg": seg, "vertex": ver}, un_pnp=False)
+    assert set(o) == {"seg", "vertex", "mask", "kpt_2d"} and o["kpt_2d"].shape == (B, K, 2)
+    np.testing.assert_array_equal(_np(o["mask"]), _np(mask_ref))
+    o = decode_keypoint({"seg": seg, "vertex": ver}, un_pnp=True)
+    assert set(o) == {"seg", "vertex", "mask", "kpt_2d", "var"} and o["var"].shape == (B, K, 2, 2)
+    if C == 2:
+        assert np.abs(_np(o["kpt_2d"]) - _np(d["kpt_2d"])).max() < 6.0
