@@ -166,6 +166,7 @@ def main():
             from clean_pvnet_amd.decode import decode_keypoint
             x = torch.randn(B, 2 + 2 * K, H, W, device=dev) * 0.1
             x[:, 1] += 3.0 * (mask != 0)
+            x[:, 0] += 3.0 * (mask == 0)
             x[:, 2:] = vertex.permute(0, 3, 4, 1, 2).reshape(B, 2 * K, H, W)
             seg, ver = x[:, :2], x[:, 2:]
 
