@@ -549,3 +549,89 @@ def test_decode_keypoint_fused_argmax_equals_unfused(oracle, synth, pkg, gpu, C)
     assert set(o) == {"seg", "vertex", "mask", "kpt_2d", "var"} and o["var"].shape == (B, K, 2, 2)
     if C == 2:
         assert np.abs(_np(o["kpt_2d"]) - _np(d["kpt_2d"])).max() < 6.0
+
+
+# --------------------------------------------------------------------------------------------------
+# the guard band of the default (bf16 matrix-core prefilter) kernel, through the batched path
+# --------------------------------------------------------------------------------------------------
+def _adversarial_image(oracle, synth, seed, thresh, hn, K=4):
+    """A cfg1-like image whose foreground directions are re-aimed so that, for every pixel not used to generate a
+    hypothesis, the cosine to some hypothesis sits within ~1e-6 (relative, in angle) of the threshold."""
+    c = {**synth.CONFIGS["cfg1"], "B": 1, "K": K, "fg": 0.12}
+    d = synth.make_batch(**c, seed=seed)
+    mask, vertex = d["mask"], d["vertex"].clone()
+    fg, coords, direct = oracle.compact_v3(_np(mask[0]), _np(vertex[0]))
+    tn = coords.shape[0]
+    rng = np.random.RandomState(seed)
+    used = rng.choice(tn, 40, replace=False)                       # hypotheses come from these pixels only
+    idxs = used[rng.randint(0, 40, size=(hn, K, 2))].astype(np.int32)
+    hyp = oracle.generate_hypothesis(direct, coords, idxs)
+    free = np.setdiff1d(np.arange(tn), used)
+    ang0 = np.arccos(np.float64(np.float32(thresh)))
+    ys, xs = coords[:, 1].astype(int), coords[:, 0].astype(int)
+    for ti in free:
+        for vi in range(K):
+            h = hyp[rng.randint(hn), vi].astype(np.float64)
+            dd = h - coords[ti]
+            if not np.isfinite(dd).all() or np.abs(dd).max() < 1e-3:
+                continue
+            base = np.arctan2(dd[1], dd[0])
+            off = ang0 * (1 + rng.uniform(-2e-6, 2e-6)) * rng.choice([-1, 1])
+            s = rng.choice([1.0, 0.37, 12.5])
+            vertex[0, ys[ti], xs[ti], vi, 0] = float(np.cos(base + off) * s)
+            vertex[0, ys[ti], xs[ti], vi, 1] = float(np.sin(base + off) * s)
+    return mask, vertex, torch.from_numpy(idxs)[None], tn
+
+
+@pytest.mark.parametrize("thresh,seed", [(0.99, 3), (0.999, 4), (0.9, 5)])
+def test_prefilter_guard_band_adversarial(oracle, synth, pkg, gpu, thresh, seed):
+    hn = 256
+    mask, vertex, idxs, tn = _adversarial_image(oracle, synth, seed, thresh, hn)
+    mean = torch.zeros(1, 4, 2)
+    det = []
+    oracle.estimate_voting_distribution_with_mean(_np(mask), _np(vertex), _np(mean), hn, hn, inlier_thresh=thresh,
+                                                  idxs=_np(idxs), details=det)
+    cov, hyp, counts, tnn = capi.estimate(mask.to(gpu), vertex.to(gpu), mean.to(gpu), hn, thresh, idxs=idxs.to(gpu))
+    want = det[0]["counts"].T
+    np.testing.assert_array_equal(_np(counts[0]), want)              # all hn*K counts bit-exact
+    assert int(_np(tnn)[0]) == tn and want.max() > 0
+    # sanity of the construction: a sizeable share of evaluations really is within 1e-5 of the threshold
+    fg, coords, direct = oracle.compact_v3(_np(mask[0]), _np(vertex[0]))
+    hy = det[0]["hypo_pts"]
+    dd = hy[:, None, :, :] - coords[None, :, None, :]                # [hn,tn,K,2]
+    cosv = (dd * direct[None]).sum(-1) / (np.linalg.norm(dd, axis=-1) * np.linalg.norm(direct, axis=-1)[None] + 1e-30)
+    near = np.abs(cosv - thresh) < 1e-5
+    assert near.sum() > 0.5 * (tn - 40) * 4
+
+
+def test_count_kernel_variants_agree(pkg):
+    """PVV_COUNT_KERNEL = bf16 (default) | fast | exact is read once per process: run the same seeded problem in three
+    subprocesses and compare every count and the means."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, json, torch
+sys.path.insert(0, %r)
+import lib; lib._register_clean_pvnet_amd()
+from clean_pvnet_amd import synth, ransac_voting as ext
+c = {**synth.CONFIGS['cfg2'], 'B': 2}
+d = synth.make_batch(**c, seed=77)
+tn = [int(x) for x in (d['mask'] != 0).sum((1, 2))]
+idxs = synth.make_idxs(tn, 512, 9, seed=77).cuda()
+m, v = d['mask'].cuda(), d['vertex'].cuda()
+out, win, tnn, ws = ext.ransac_voting_v3(m, v, 512, 0.99, 5, 30000, idxs, None, 0, ext.SINGULAR_REFERENCE)
+cov, hyp, counts, t2 = ext.estimate_voting_distribution(m, v, out, 512, 0.99, 5, 30000, idxs, None, 0, True)
+print(json.dumps(dict(out=out.cpu().tolist(), win=win.cpu().tolist(), csum=int(counts.sum()),
+                      chash=int((counts.long() * torch.arange(counts.numel(), device='cuda').view_as(counts) %% 1000003).sum()))))
+""" % root
+    res = {}
+    for k in ("bf16", "fast", "exact"):
+        env = dict(os.environ, PVV_COUNT_KERNEL=k)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[k] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["bf16"] == res["fast"] == res["exact"]
+    assert res["exact"]["csum"] > 0
