@@ -134,7 +134,7 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": "k_count_inliers", "kernel_ms_avg": round(k_avg_ms, 4),
+                    "kernel": {"exact": "k_count_inliers", "fast": "k_count_fast"}.get(os.environ.get("PVV_COUNT_KERNEL", ""), "k_count_bf16"), "kernel_ms_avg": round(k_avg_ms, 4),
                     "kernel_ms_median": round(k_ms[len(k_ms) // 2], 4), "algorithmic_bytes": alg_bytes,
                     "evaluations": evals, "gevals_per_s": round(evals / (k_avg_ms * 1e-3) / 1e9, 1)}
 
