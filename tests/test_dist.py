@@ -47,6 +47,10 @@ def _worker(rank, world, port, batch, q):
             out = pdist.gather_results(torch.zeros(0, cfg["K"], 2), batch)
         cov_local = torch.arange((hi - lo) * cfg["K"] * 4, dtype=torch.float32).view(hi - lo, cfg["K"], 2, 2) + 1000 * rank
         cov = pdist.gather_results(cov_local, batch)
+        # async form (what bench.py uses to overlap the exchange with the next batch's voting)
+        cov2, work = pdist.gather_results(cov_local, batch, async_op=True)
+        work.wait()
+        assert torch.equal(cov2, cov)
         q.put((rank, out.numpy(), cov.numpy()))
     finally:
         dist.destroy_process_group()
