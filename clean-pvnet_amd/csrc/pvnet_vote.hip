@@ -463,6 +463,53 @@ __global__ __launch_bounds__(kBlock) void k_gen_hypothesis(
 // The number of items depends on tn[b], which only the device knows, so the grid is persistent
 // and every block derives the item list from tn[] itself (no host sync, no empty blocks).
 // ---------------------------------------------------------------------------------------------
+// ---- work-item table of the persistent count kernels ---------------------------------------------------------
+// The number of pixel chunks of an image depends on tn[b], which only the device knows, so every block builds the
+// same table itself: item_end[b] = inclusive prefix of (chunks of image b) * items_per_chunk.  No host sync, no
+// empty blocks.  Returns the total number of items (valid in every thread after the barrier inside).
+constexpr int kMaxBatchLds = 1024;  // images per launch (the table lives in LDS)
+
+__device__ __forceinline__ int build_item_table(int *item_end, const int *__restrict__ tn_arr, int tn_fixed, int B,
+                                                int pixels_per_chunk, int items_per_chunk)
+{
+    const int lane = lane_id();
+    if (wave_id() == 0) {
+        int carry = 0;
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            const int b = b0 + lane;
+            int n = 0;
+            if (b < B) {
+                const int tn = tn_arr ? tn_arr[b] : tn_fixed;
+                n = ((tn + pixels_per_chunk - 1) / pixels_per_chunk) * items_per_chunk;
+            }
+            int inc = n;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int m = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += m;
+            }
+            inc += carry;
+            if (b < B) item_end[b] = inc;
+            carry = __builtin_amdgcn_readlane(inc, 63);
+        }
+    }
+    __syncthreads();
+    return item_end[B - 1];
+}
+
+// image of work item `item` (first b with item_end[b] > item) and the item's index within that image
+__device__ __forceinline__ int locate_item(const int *item_end, int B, int item, int *local)
+{
+    int lo = 0, hi = B - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (item_end[mid] > item) hi = mid; else lo = mid + 1;
+    }
+    const int b = __builtin_amdgcn_readfirstlane(lo);
+    *local = __builtin_amdgcn_readfirstlane(item - (b ? item_end[b - 1] : 0));
+    return b;
+}
+
 struct CountArgs {
     const float2 *coords;  // pixel p of image b: coords[b*c_b + p]
     const float2 *dirs;    // dirs[b*d_b + vi*d_v + p*d_p]
@@ -475,8 +522,6 @@ struct CountArgs {
     float thresh;
 };
 
-constexpr int kMaxBatchLds = 1024;  // images per launch (item prefix lives in LDS)
-
 template <int R>
 __global__ __launch_bounds__(kBlock) void k_count_inliers(CountArgs a)
 {
@@ -487,39 +532,11 @@ __global__ __launch_bounds__(kBlock) void k_count_inliers(CountArgs a)
     const int nht = (a.hn + HT - 1) / HT;
     const int per_chunk = a.K * nht;
 
-    // inclusive scan of items per image (wave 0, 64 images per step)
-    if (wave == 0) {
-        int carry = 0;
-        for (int b0 = 0; b0 < a.B; b0 += 64) {
-            int b = b0 + lane;
-            int n = 0;
-            if (b < a.B) {
-                int tn = a.tn_arr ? a.tn_arr[b] : a.tn_fixed;
-                n = ((tn + PC - 1) / PC) * per_chunk;
-            }
-            int inc = n;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int m = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += m;
-            }
-            inc += carry;
-            if (b < a.B) item_end[b] = inc;
-            carry = __builtin_amdgcn_readlane(inc, 63);
-        }
-    }
-    __syncthreads();
-    const int total = item_end[a.B - 1];
+    const int total = build_item_table(item_end, a.tn_arr, a.tn_fixed, a.B, PC, per_chunk);
 
     for (int item = blockIdx.x; item < total; item += gridDim.x) {
-        // image of this item: first b with item_end[b] > item
-        int lo = 0, hi = a.B - 1;
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (item_end[mid] > item) hi = mid; else lo = mid + 1;
-        }
-        const int b = __builtin_amdgcn_readfirstlane(lo);
-        const int local = __builtin_amdgcn_readfirstlane(item - (b ? item_end[b - 1] : 0));
+        int local;
+        const int b = locate_item(item_end, a.B, item, &local);
         const int chunk = local / per_chunk;
         const int rem = local - chunk * per_chunk;
         const int vi = rem / nht;
@@ -658,34 +675,11 @@ __global__ __launch_bounds__(kBlock) void k_count_fast(
     const int pix_per_wave = __builtin_amdgcn_readfirstlane(s_ppw);
     const int PC = 4 * pix_per_wave;
 
-    if (wave == 0) {
-        int carry = 0;
-        for (int b0 = 0; b0 < B; b0 += 64) {
-            int b = b0 + lane;
-            int n = 0;
-            if (b < B) n = ((tn_arr[b] + PC - 1) / PC) * per_chunk;
-            int inc = n;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int m = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += m;
-            }
-            inc += carry;
-            if (b < B) item_end[b] = inc;
-            carry = __builtin_amdgcn_readlane(inc, 63);
-        }
-    }
-    __syncthreads();
-    const int total = item_end[B - 1];
+    const int total = build_item_table(item_end, tn_arr, 0, B, PC, per_chunk);
 
     for (int item = blockIdx.x; item < total; item += gridDim.x) {
-        int lo = 0, hi = B - 1;
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (item_end[mid] > item) hi = mid; else lo = mid + 1;
-        }
-        const int b = __builtin_amdgcn_readfirstlane(lo);
-        const int local = __builtin_amdgcn_readfirstlane(item - (b ? item_end[b - 1] : 0));
+        int local;
+        const int b = locate_item(item_end, B, item, &local);
         const int chunk = local / per_chunk;
         const int rem = local - chunk * per_chunk;
         const int vi = rem / nht;
@@ -863,35 +857,12 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
     const int nhg = (nt + htpi - 1) / htpi;
     const int per_chunk = K * nhg;
 
-    if (wave == 0) {
-        int carry = 0;
-        for (int b0 = 0; b0 < B; b0 += 64) {
-            int b = b0 + lane;
-            int n = 0;
-            if (b < B) n = ((tn_arr[b] + PC - 1) / PC) * per_chunk;
-            int inc = n;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int m = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += m;
-            }
-            inc += carry;
-            if (b < B) item_end[b] = inc;
-            carry = __builtin_amdgcn_readlane(inc, 63);
-        }
-    }
-    __syncthreads();
-    const int total = item_end[B - 1];
+    const int total = build_item_table(item_end, tn_arr, 0, B, PC, per_chunk);
     const int col = lane & 31, kslice = lane >> 5;
 
     for (int item = blockIdx.x; item < total; item += gridDim.x) {
-        int lo = 0, hi = B - 1;
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (item_end[mid] > item) hi = mid; else lo = mid + 1;
-        }
-        const int b = __builtin_amdgcn_readfirstlane(lo);
-        const int local = __builtin_amdgcn_readfirstlane(item - (b ? item_end[b - 1] : 0));
+        int local;
+        const int b = locate_item(item_end, B, item, &local);
         const int chunk = local / per_chunk;
         const int rem = local - chunk * per_chunk;
         const int vi = rem / nhg;
