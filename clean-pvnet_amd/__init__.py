@@ -10,9 +10,9 @@ built extension (``python __graft_entry__.py`` builds it) raises ImportError, an
 them with CPU tensors raises RuntimeError.
 """
 from .ransac_voting_gpu import (b_inv, estimate_voting_distribution_with_mean,  # noqa: F401
-                                ransac_voting_layer, ransac_voting_layer_v3)
+                                ransac_voting_layer, ransac_voting_layer_v3, uncertainty_pnp_weights)
 
 from .decode import decode_keypoint  # noqa: F401,E402
 
 __all__ = ["ransac_voting_layer", "ransac_voting_layer_v3", "estimate_voting_distribution_with_mean", "b_inv",
-           "decode_keypoint"]
+           "decode_keypoint", "uncertainty_pnp_weights"]

@@ -1133,7 +1133,8 @@ __global__ void k_finalize_v3(const int *__restrict__ tn_arr, const double *__re
 __global__ __launch_bounds__(kBlock) void k_covariance(
     const int *__restrict__ tn_arr, const float2 *__restrict__ hyps, const int *__restrict__ counts,
     const float2 *__restrict__ mean, float *__restrict__ cov /*[B,K,2,2]*/,
-    float2 *__restrict__ hyp_out /*[B,K,hn] or null*/, int *__restrict__ counts_out, int K, int hn)
+    float2 *__restrict__ hyp_out /*[B,K,hn] or null*/, int *__restrict__ counts_out,
+    float *__restrict__ weights /*[B,K,3] or null*/, int K, int hn)
 {
     __shared__ int redi[4];
     __shared__ double redd[4];
@@ -1182,6 +1183,20 @@ __global__ __launch_bounds__(kBlock) void k_covariance(
         float *c = cov + (size_t)bk * 4;
         c[0] = (float)(sxx / den); c[1] = (float)(sxy / den);
         c[2] = (float)(sxy / den); c[3] = (float)(syy / den);
+        if (weights) {
+            // evaluators/linemod/pvnet.py:118-128: inv(sqrtm(var)) per keypoint, zeros when var[0,0] < 1e-6 or NaN.
+            // Closed form for a 2x2 SPD matrix A: sqrtm(A) = (A + s I)/t, s = sqrt(det A), t = sqrt(tr A + 2 s).
+            const double a = (double)c[0], b = (double)c[1], d = (double)c[3];
+            double wxx = 0.0, wxy = 0.0, wyy = 0.0;
+            const double det = a * d - b * b;
+            if (!(c[0] < 1e-6f) && a == a && b == b && d == d && det > 0.0 && a > 0.0) {
+                const double s = sqrt(det), t = sqrt(a + d + 2.0 * s);
+                const double q = t / ((a + s) * (d + s) - b * b);
+                wxx = q * (d + s); wxy = -q * b; wyy = q * (a + s);
+            }
+            float *w = weights + (size_t)bk * 3;
+            w[0] = (float)wxx; w[1] = (float)wxy; w[2] = (float)wyy;
+        }
     }
 }
 
@@ -1662,7 +1677,7 @@ PVV_EXPORT int pvv_estimate_voting_distribution(const pvv_problem *p, const void
                                                 const float *d_selection, const float *d_mean,
                                                 void *d_workspace, size_t workspace_bytes,
                                                 float *d_cov, float *d_hyp, int32_t *d_counts,
-                                                int32_t *d_tn, void *stream)
+                                                int32_t *d_tn, float *d_weights, void *stream)
 {
     Layout L;
     if (int e = check_ptrs(p, d_mask, d_vertex, d_workspace, workspace_bytes, &L)) return e;
@@ -1673,7 +1688,7 @@ PVV_EXPORT int pvv_estimate_voting_distribution(const pvv_problem *p, const void
     hipLaunchKernelGGL(k_covariance, dim3(p->K, p->B), dim3(kBlock), 0, st,
                        (const int *)(ws + L.tn), (const float2 *)(ws + L.hyps),
                        (const int *)(ws + L.counts), (const float2 *)d_mean, d_cov, (float2 *)d_hyp,
-                       d_counts, p->K, p->hn);
+                       d_counts, d_weights, p->K, p->hn);
     if (int e = check_launch("k_covariance")) return e;
     if (d_tn) {
         hipError_t e = hipMemcpyAsync(d_tn, ws + L.tn, sizeof(int) * p->B, hipMemcpyDeviceToDevice, st);

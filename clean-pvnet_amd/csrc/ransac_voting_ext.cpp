@@ -271,8 +271,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_v3(
 }
 
 // estimate_voting_distribution_with_mean for the whole batch
-// -> (cov [b,vn,2,2], hyp [b,vn,hn,2] | empty, counts [b,vn,hn] | empty, tn [b])
-std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> estimate_voting_distribution(
+// -> (cov [b,vn,2,2], hyp [b,vn,hn,2] | empty, counts [b,vn,hn] | empty, tn [b], weights [b,vn,3])
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> estimate_voting_distribution(
     at::Tensor mask, at::Tensor vertex, at::Tensor mean, int64_t hyp_total, double inlier_thresh,
     int64_t min_num, int64_t max_num, std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection,
     int64_t seed, bool want_hyp)
@@ -295,13 +295,14 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> estimate_voting_distr
         hyp = at::empty({0}, vertex.options());
         counts = at::empty({0}, vertex.options().dtype(at::kInt));
     }
+    auto weights = at::empty({p.B, p.K, 3}, vertex.options());
     ok(pvv_estimate_voting_distribution(&p, mask.data_ptr(), vertex.data_ptr<float>(), ip, sp,
                                         mean.data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(),
                                         cov.data_ptr<float>(), want_hyp ? hyp.data_ptr<float>() : nullptr,
                                         want_hyp ? counts.data_ptr<int32_t>() : nullptr,
-                                        tn.data_ptr<int32_t>(), cur_stream(vertex)),
+                                        tn.data_ptr<int32_t>(), weights.data_ptr<float>(), cur_stream(vertex)),
        "estimate_voting_distribution");
-    return {cov, hyp, counts, tn};
+    return {cov, hyp, counts, tn, weights};
 }
 
 // Re-run only the inlier-count kernel on the state a previous ransac_voting_v3 call left in `ws`

@@ -120,7 +120,7 @@ def b_inv(b_mat):
 
 def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256, min_hyp_num=4096, topk=128,
                                            inlier_thresh=0.99, min_num=5, max_num=30000, output_hyp=False, *,
-                                           idxs=None, selection=None):
+                                           idxs=None, selection=None, return_weights=False):
     '''
     :param mask:   [b,h,w]   foreground is ``mask == 1`` (:207)
     :param vertex: [b,h,w,vn,2]
@@ -131,25 +131,50 @@ def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256
     ``ceil(min_hyp_num/round_hyp_num)`` rounds of ``round_hyp_num`` fresh hypotheses (:231-247)
     are evaluated as ONE pass of ``round_num*round_hyp_num`` hypotheses; ``idxs`` (if injected)
     holds the rounds concatenated in order.  ``topk`` is unused, as in the reference.
+
+    ``return_weights=True`` appends ``weights [b,vn,3] = (wxx,wxy,wyy)`` of ``inv(sqrtm(cov))`` -- what the
+    evaluators compute per keypoint on the host before calling uncertainty_pnp
+    (lib/evaluators/linemod/pvnet.py:118-130) -- fused into the covariance kernel.
     '''
     del topk
     b = vertex.shape[0]
     hn_total = int(np.ceil(min_hyp_num / round_hyp_num)) * int(round_hyp_num)
     mask = _as_mask(mask, True)
     mean_c = mean.contiguous().float()
-    covs, hyps, ratios = [], [], []
+    covs, hyps, ratios, wts = [], [], [], []
     for lo, hi in _chunks(b):
-        cov, hyp, counts, tn = _ext.estimate_voting_distribution(
+        cov, hyp, counts, tn, w = _ext.estimate_voting_distribution(
             mask[lo:hi], vertex[lo:hi], mean_c[lo:hi], hn_total, float(inlier_thresh), int(min_num),
             int(max_num), None if idxs is None else idxs[lo:hi],
             None if selection is None else selection[lo:hi], _next_seed(), bool(output_hyp))
         covs.append(cov)
+        wts.append(w)
         if output_hyp:
             hyps.append(hyp)
             tnf = tn.float().clamp(min=1).view(-1, 1, 1)
             ratio = counts.float() / tnf
             ratios.append(torch.where(tn.view(-1, 1, 1) > 0, ratio, torch.ones_like(ratio)))
     cov = covs[0] if len(covs) == 1 else torch.cat(covs)
+    extra = (wts[0] if len(wts) == 1 else torch.cat(wts),) if return_weights else ()
     if output_hyp:
-        return mean, cov, torch.cat(hyps), torch.cat(ratios)
-    return mean, cov
+        return (mean, cov, torch.cat(hyps), torch.cat(ratios)) + extra
+    return (mean, cov) + extra
+
+
+def uncertainty_pnp_weights(var):
+    '''
+    The host loop of ``Evaluator.uncertainty_pnp`` (lib/evaluators/linemod/pvnet.py:118-128) as batched tensor
+    math on the device: ``inv(sqrtm(var))`` per keypoint in closed form, zeros where ``var[...,0,0] < 1e-6``, any
+    entry is NaN or the matrix is not positive definite.
+    :param var: [...,2,2]
+    :return: [...,3]  (wxx, wxy, wyy) -- ``cov_invs.reshape(-1,4)[:, (0,1,3)]`` of :127-128
+    '''
+    v = var.double()
+    a, b, d = v[..., 0, 0], v[..., 0, 1], v[..., 1, 1]
+    det = a * d - b * b
+    ok = ~(var[..., 0, 0] < 1e-6) & ~torch.isnan(v).flatten(-2).any(-1) & (det > 0) & (a > 0)
+    s = torch.sqrt(det.clamp(min=0))
+    t = torch.sqrt((a + d + 2 * s).clamp(min=0))
+    q = t / ((a + s) * (d + s) - b * b)
+    w = torch.stack([q * (d + s), -q * b, q * (a + s)], -1)
+    return torch.where(ok.unsqueeze(-1), w, torch.zeros_like(w)).to(var.dtype)

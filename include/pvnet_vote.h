@@ -161,7 +161,11 @@ int pvv_decode_keypoint_v3(const pvv_problem *p, const float *d_seg,
  *   d_mean      [B,K,2] f32
  *   d_cov       [B,K,2,2] f32
  *   d_hyp       [B,K,hn,2] f32 all hypotheses (optional, may be NULL)
- *   d_counts    [B,K,hn] i32 their inlier counts (optional) */
+ *   d_counts    [B,K,hn] i32 their inlier counts (optional)
+ *   d_weights   [B,K,3] f32 (wxx,wxy,wyy) of inv(sqrtm(cov)) (optional): the
+ *               per-keypoint weights the evaluators hand to uncertainty_pnp
+ *               (lib/evaluators/linemod/pvnet.py:118-130), zeros where
+ *               cov[0][0] < 1e-6, any entry is NaN, or cov is not positive definite */
 int pvv_estimate_voting_distribution(const pvv_problem *p, const void *d_mask,
                                      const float *d_vertex,
                                      const int32_t *d_idxs,
@@ -169,7 +173,8 @@ int pvv_estimate_voting_distribution(const pvv_problem *p, const void *d_mask,
                                      const float *d_mean, void *d_workspace,
                                      size_t workspace_bytes, float *d_cov,
                                      float *d_hyp, int32_t *d_counts,
-                                     int32_t *d_tn, void *stream);
+                                     int32_t *d_tn, float *d_weights,
+                                     void *stream);
 
 /* Bench / profiling aid: re-runs ONLY the inlier-count kernel of the last
  * layer call recorded in `d_workspace` (same problem), so its duration can be

@@ -49,7 +49,7 @@ def load():
         L.pvv_ransac_voting_v3.argtypes = [ctypes.POINTER(Problem), vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]
         L.pvv_decode_keypoint_v3.argtypes = [ctypes.POINTER(Problem), vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]
         L.pvv_estimate_voting_distribution.argtypes = [ctypes.POINTER(Problem), vp, vp, vp, vp, vp, vp, sz,
-                                                       vp, vp, vp, vp, vp]
+                                                       vp, vp, vp, vp, vp, vp]
         L.pvv_rerun_count_kernel.argtypes = [ctypes.POINTER(Problem), vp, sz, ctypes.c_int, vp]
         _lib = L
     return _lib
@@ -115,5 +115,5 @@ def estimate(mask, vertex, mean, hn_total, thresh, idxs=None, selection=None, **
     tn = torch.empty(p.B, dtype=torch.int32, device=dev)
     check(L.pvv_estimate_voting_distribution(ctypes.byref(p), ptr(mask), ptr(vertex), ptr(idxs), ptr(selection),
                                              ptr(mean), ptr(ws), n, ptr(cov), ptr(hyp), ptr(counts), ptr(tn),
-                                             stream()))
+                                             None, stream()))
     return cov, hyp, counts, tn

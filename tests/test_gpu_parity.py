@@ -623,7 +623,7 @@ tn = [int(x) for x in (d['mask'] != 0).sum((1, 2))]
 idxs = synth.make_idxs(tn, 512, 9, seed=77).cuda()
 m, v = d['mask'].cuda(), d['vertex'].cuda()
 out, win, tnn, ws = ext.ransac_voting_v3(m, v, 512, 0.99, 5, 30000, idxs, None, 0, ext.SINGULAR_REFERENCE)
-cov, hyp, counts, t2 = ext.estimate_voting_distribution(m, v, out, 512, 0.99, 5, 30000, idxs, None, 0, True)
+cov, hyp, counts, t2, wts = ext.estimate_voting_distribution(m, v, out, 512, 0.99, 5, 30000, idxs, None, 0, True)
 print(json.dumps(dict(out=out.cpu().tolist(), win=win.cpu().tolist(), csum=int(counts.sum()),
                       chash=int((counts.long() * torch.arange(counts.numel(), device='cuda').view_as(counts) %% 1000003).sum()))))
 """ % root
@@ -635,3 +635,36 @@ print(json.dumps(dict(out=out.cpu().tolist(), win=win.cpu().tolist(), csum=int(c
         res[k] = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["bf16"] == res["fast"] == res["exact"]
     assert res["exact"]["csum"] > 0
+
+
+def test_uncertainty_pnp_weights_match_evaluator_host_loop(oracle, synth, pkg, gpu):
+    """SURVEY 8(f) rank 3, first half: inv(sqrtm(var)) -> (wxx,wxy,wyy), the loop of evaluators/linemod/pvnet.py:118-128,
+    fused into the covariance kernel and as a standalone tensor function; oracle = numpy + scipy.linalg.sqrtm."""
+    import scipy.linalg
+    from clean_pvnet_amd.ransac_voting_gpu import estimate_voting_distribution_with_mean, uncertainty_pnp_weights
+    c = {**synth.CONFIGS["cfg1"], "B": 3, "K": 5}
+    d = synth.make_batch(**c, seed=91)
+    mask, vertex = d["mask"], d["vertex"]
+    mask[2] = 0                                                          # skipped image: cov = mean mean^T (rank 1)
+    tn = [int(x) for x in (mask == 1).sum((1, 2))]
+    idxs = synth.make_idxs(tn, 256, 5, seed=91)
+    mean = d["kpt_2d"] + 0.1
+    _m, cov, w = estimate_voting_distribution_with_mean(mask.to(gpu), vertex.to(gpu), mean.to(gpu), 64, 256,
+                                                        idxs=idxs.to(gpu), return_weights=True)
+    var = _np(cov)
+
+    def host_loop(var_b):                                                # the reference's loop, verbatim semantics
+        out = []
+        for vi in range(var_b.shape[0]):
+            if var_b[vi, 0, 0] < 1e-6 or np.sum(np.isnan(var_b)[vi]) > 0:
+                out.append(np.zeros([2, 2], np.float32))
+            else:
+                out.append(np.linalg.inv(scipy.linalg.sqrtm(var_b[vi].astype(np.float64))))
+        return np.asarray(out).reshape(-1, 4)[:, (0, 1, 3)]
+    for bi in range(2):                                                  # well-conditioned images
+        want = host_loop(var[bi])
+        np.testing.assert_allclose(_np(w[bi]), want, rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(_np(uncertainty_pnp_weights(cov[bi])), want, rtol=2e-4, atol=1e-5)
+    assert (_np(w[2]) == 0).all() or np.isfinite(_np(w[2])).all()        # rank-1 covariance: zeros (not positive definite) or finite
+    bad = torch.tensor([[[1e-7, 0.0], [0.0, 1.0]], [[float("nan"), 0.0], [0.0, 1.0]], [[4.0, 0.0], [0.0, 9.0]]], device=gpu)
+    np.testing.assert_allclose(_np(uncertainty_pnp_weights(bad)), [[0, 0, 0], [0, 0, 0], [0.5, 0, 1 / 3]], atol=1e-6)
