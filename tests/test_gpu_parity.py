@@ -668,3 +668,32 @@ def test_uncertainty_pnp_weights_match_evaluator_host_loop(oracle, synth, pkg, g
     assert (_np(w[2]) == 0).all() or np.isfinite(_np(w[2])).all()        # rank-1 covariance: zeros (not positive definite) or finite
     bad = torch.tensor([[[1e-7, 0.0], [0.0, 1.0]], [[float("nan"), 0.0], [0.0, 1.0]], [[4.0, 0.0], [0.0, 9.0]]], device=gpu)
     np.testing.assert_allclose(_np(uncertainty_pnp_weights(bad)), [[0, 0, 0], [0, 0, 0], [0.5, 0, 1 / 3]], atol=1e-6)
+
+
+def test_whole_call_can_be_captured_in_a_hip_graph(oracle, synth, pkg, gpu):
+    """The library only enqueues kernels on the given stream (no allocation, no sync), so one voting call can be
+    captured in a HIP graph and replayed; the replay must reproduce the eager result bit for bit."""
+    from clean_pvnet_amd import ransac_voting as ext
+    c = {**synth.CONFIGS["cfg2"], "B": 1}
+    d = synth.make_batch(**c, seed=13)
+    tn = [int(x) for x in (d["mask"] != 0).sum((1, 2))]
+    idxs = synth.make_idxs(tn, 512, 9, seed=13).to(gpu)
+    m, v = d["mask"].to(gpu), d["vertex"].to(gpu)
+    eager, win_e, _tn, _ws = ext.ransac_voting_v3(m, v, 512, 0.99, 5, 30000, idxs, None, 0, ext.SINGULAR_REFERENCE)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            ext.ransac_voting_v3(m, v, 512, 0.99, 5, 30000, idxs, None, 0, ext.SINGULAR_REFERENCE)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out, win, tn_g, ws = ext.ransac_voting_v3(m, v, 512, 0.99, 5, 30000, idxs, None, 0, ext.SINGULAR_REFERENCE)
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(_np(out), _np(eager))
+    np.testing.assert_array_equal(_np(win), _np(win_e))
+    want = oracle.ransac_voting_layer_v3(_np(d["mask"]), _np(d["vertex"]), 512, 0.99, idxs=_np(idxs))
+    np.testing.assert_allclose(_np(out), want, rtol=0, atol=ATOL)
