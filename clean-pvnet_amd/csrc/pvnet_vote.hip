@@ -1031,24 +1031,27 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
 // Stage 4 (v3): winner selection + least-squares refit (P:159-167 and P:176-196).
 // One block per (keypoint, image).
 // ---------------------------------------------------------------------------------------------
+// kRefitSplit blocks per (keypoint, image), each over a quarter of the pixels: the exact re-vote is a long
+// dependent chain (two sqrt, one divide) and 576 blocks alone leave the SIMDs latency-bound.  Partial sums go to
+// sums[b,vi,split,5] and are merged in a fixed order by k_finalize_v3 (deterministic).
+constexpr int kRefitSplit = 4;
+
 __global__ __launch_bounds__(kBlock) void k_select_refit(
     const int *__restrict__ tn_arr, const float2 *__restrict__ coords,
     const float2 *__restrict__ dirs, const float2 *__restrict__ hyps,
-    const int *__restrict__ counts, double *__restrict__ sums /*[B,K,5]*/,
-    int *__restrict__ singular /*[B,K]*/, float2 *__restrict__ pts /*[B,K]*/,
+    const int *__restrict__ counts, double *__restrict__ sums /*[B,K,kRefitSplit,5]*/,
     int *__restrict__ win_counts /*[B,K] or null*/, int K, int hn, int cap, float thresh)
 {
     __shared__ int s_cnt[4], s_idx[4];
-    __shared__ double redd[4];
-    const int vi = blockIdx.x, b = blockIdx.y;
+    __shared__ double red5[20];
+    const int vi = blockIdx.x / kRefitSplit, split = blockIdx.x % kRefitSplit, b = blockIdx.y;
     const int bk = b * K + vi;
     const int tn = tn_arr[b];
+    double *part = sums + ((size_t)bk * kRefitSplit + split) * 5;
     if (tn <= 0) {
         if (threadIdx.x == 0) {
-            for (int i = 0; i < 5; ++i) sums[(size_t)bk * 5 + i] = 0.0;
-            singular[bk] = 0;
-            pts[bk] = make_float2(0.f, 0.f);
-            if (win_counts) win_counts[bk] = 0;
+            for (int i = 0; i < 5; ++i) part[i] = 0.0;
+            if (win_counts && split == 0) win_counts[bk] = 0;
         }
         return;
     }
@@ -1079,52 +1082,106 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
     const float2 *dp = dirs + (size_t)bk * cap;
     const float2 *cq = coords + (size_t)b * cap;
     double xx = 0, xy = 0, yy = 0, bx = 0, by = 0;
-    for (int ti = threadIdx.x; ti < tn; ti += kBlock) {
-        float2 d = dp[ti], c = cq[ti];
-        if (!vote_exact(c.x, c.y, win.x, win.y, d.x, d.y, thresh)) continue;
-        double nx = (double)d.y, ny = -(double)d.x;          // P:178-179
-        double bb = nx * (double)c.x + ny * (double)c.y;     // P:189
-        xx += nx * nx; xy += nx * ny; yy += ny * ny;         // P:190
-        bx += nx * bb; by += ny * bb;                        // P:191
-    }
-    xx = block_sum(xx, redd); xy = block_sum(xy, redd); yy = block_sum(yy, redd);
-    bx = block_sum(bx, redd); by = block_sum(by, redd);
-    if (threadIdx.x == 0) {
-        double *s = sums + (size_t)bk * 5;
-        s[0] = xx; s[1] = xy; s[2] = yy; s[3] = bx; s[4] = by;
-        double det = xx * yy - xy * xy;
-        bool sing = !(det != 0.0) || !isfinite(det);
-        singular[bk] = sing ? 1 : 0;
-        float2 o = make_float2(0.f, 0.f);
-        if (!sing) {
-            o.x = (float)((yy * bx - xy * by) / det);        // P:193, closed-form 2x2
-            o.y = (float)((xx * by - xy * bx) / det);
+    // this block's quarter of the pixels; four pixels per trip so that the loads of a trip overlap
+    const int per = (tn + kRefitSplit - 1) / kRefitSplit;
+    const int tbeg = split * per, tend = min(tn, tbeg + per);
+    for (int t0 = tbeg + threadIdx.x; t0 < tend; t0 += 4 * kBlock) {
+        float2 d[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ti = t0 + u * kBlock;
+            d[u] = ti < tend ? dp[ti] : make_float2(0.f, 0.f);  // zero direction: norm1 < 1e-6, never an inlier
+            c[u] = ti < tend ? cq[ti] : make_float2(0.f, 0.f);
         }
-        pts[bk] = o;
-        if (win_counts) win_counts[bk] = best;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!vote_exact(c[u].x, c[u].y, win.x, win.y, d[u].x, d[u].y, thresh)) continue;
+            double nx = (double)d[u].y, ny = -(double)d[u].x;          // P:178-179
+            double bb = nx * (double)c[u].x + ny * (double)c[u].y;     // P:189
+            xx += nx * nx; xy += nx * ny; yy += ny * ny;               // P:190
+            bx += nx * bb; by += ny * bb;                              // P:191
+        }
     }
+    // one reduction for all five sums: five independent shuffle chains interleave, a single barrier
+    double v[5] = {xx, xy, yy, bx, by};
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v[i] += __shfl_xor(v[i], o, 64);
+    }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) red5[(threadIdx.x >> 6) * 5 + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) part[threadIdx.x] = red5[threadIdx.x] + red5[5 + threadIdx.x] + red5[10 + threadIdx.x] + red5[15 + threadIdx.x];
+    if (threadIdx.x == 0 && win_counts && split == 0) win_counts[bk] = best;
 }
 
-// Singular-matrix policy across the keypoints of an image (b_inv, P:97-109).
-__global__ void k_finalize_v3(const int *__restrict__ tn_arr, const double *__restrict__ sums,
-                              const int *__restrict__ singular, const float2 *__restrict__ pts,
-                              float2 *__restrict__ out, int B, int K, int policy)
+// Merge the partial normal equations, solve the 2x2 systems (P:193, closed form in binary64) and apply the
+// singular-matrix policy across the keypoints of an image (b_inv, P:97-109).  One block per image.
+__global__ __launch_bounds__(64) void k_finalize_v3(const int *__restrict__ tn_arr, const double *__restrict__ sums,
+                                                    float2 *__restrict__ out, int K, int policy)
 {
-    int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= B * K) return;
-    int b = gid / K;
-    float2 o = pts[gid];
-    if (tn_arr[b] > 0 && policy != PVV_SINGULAR_ZERO) {
-        bool any = false;
-        for (int vi = 0; vi < K; ++vi) any |= singular[b * K + vi] != 0;
-        if (any) {
-            if (policy == PVV_SINGULAR_REFERENCE)  // inverse := identity  =>  x = ATb
-                o = make_float2((float)sums[(size_t)gid * 5 + 3], (float)sums[(size_t)gid * 5 + 4]);
-            else                                   // v1: the whole image becomes zeros
-                o = make_float2(0.f, 0.f);
+    __shared__ int any_singular;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) any_singular = 0;
+    __syncthreads();
+    const bool skipped = tn_arr[b] <= 0;
+    for (int v0 = 0; v0 < K; v0 += 64) {          // K <= 64 in every real use: one trip
+        const int vi = v0 + threadIdx.x;
+        float2 o = make_float2(0.f, 0.f);
+        double bx = 0, by = 0;
+        bool sing = false;
+        if (vi < K && !skipped) {
+            const double *q = sums + ((size_t)b * K + vi) * kRefitSplit * 5;
+            double xx = 0, xy = 0, yy = 0;
+            for (int sp = 0; sp < kRefitSplit; ++sp) {
+                xx += q[sp * 5]; xy += q[sp * 5 + 1]; yy += q[sp * 5 + 2]; bx += q[sp * 5 + 3]; by += q[sp * 5 + 4];
+            }
+            const double det = xx * yy - xy * xy;
+            sing = !(det != 0.0) || !isfinite(det);
+            if (!sing) {
+                o.x = (float)((yy * bx - xy * by) / det);
+                o.y = (float)((xx * by - xy * bx) / det);
+            }
         }
+        if (K > 64) {   // generic path: the policy needs every keypoint's flag first
+            if (sing) atomicOr(&any_singular, 1);
+            continue;
+        }
+        if (sing) any_singular = 1;
+        __syncthreads();
+        if (vi < K) {
+            if (!skipped && any_singular && policy != PVV_SINGULAR_ZERO) {
+                if (policy == PVV_SINGULAR_REFERENCE) o = make_float2((float)bx, (float)by);   // inverse := identity => x = ATb
+                else o = make_float2(0.f, 0.f);                                                // v1: the whole image becomes zeros
+            }
+            out[(size_t)b * K + vi] = o;
+        }
+        return;
     }
-    out[gid] = o;
+    // K > 64: second pass now that any_singular is complete
+    __syncthreads();
+    for (int vi = threadIdx.x; vi < K; vi += 64) {
+        float2 o = make_float2(0.f, 0.f);
+        if (!skipped) {
+            const double *q = sums + ((size_t)b * K + vi) * kRefitSplit * 5;
+            double xx = 0, xy = 0, yy = 0, bx = 0, by = 0;
+            for (int sp = 0; sp < kRefitSplit; ++sp) {
+                xx += q[sp * 5]; xy += q[sp * 5 + 1]; yy += q[sp * 5 + 2]; bx += q[sp * 5 + 3]; by += q[sp * 5 + 4];
+            }
+            const double det = xx * yy - xy * xy;
+            const bool sing = !(det != 0.0) || !isfinite(det);
+            if (!sing) {
+                o.x = (float)((yy * bx - xy * by) / det);
+                o.y = (float)((xx * by - xy * bx) / det);
+            }
+            if (any_singular && policy != PVV_SINGULAR_ZERO)
+                o = policy == PVV_SINGULAR_REFERENCE ? make_float2((float)bx, (float)by) : make_float2(0.f, 0.f);
+        }
+        out[(size_t)b * K + vi] = o;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1316,7 +1373,7 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
     int T;
-    size_t tile_nz, tile_sum, bits, tn, coords, dirs, recs, hyps, counts, sums, singular, pts, total;
+    size_t tile_nz, tile_sum, bits, tn, coords, dirs, recs, hyps, counts, sums, total;
 };
 
 Layout make_layout(const pvv_problem *p)
@@ -1335,9 +1392,7 @@ Layout make_layout(const pvv_problem *p)
     L.recs = take(sizeof(PixelRec) * (size_t)p->B * p->K * p->cap);
     L.hyps = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
     L.counts = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
-    L.sums = take(sizeof(double) * (size_t)p->B * p->K * 5);
-    L.singular = take(sizeof(int) * (size_t)p->B * p->K);
-    L.pts = take(sizeof(float2) * (size_t)p->B * p->K);
+    L.sums = take(sizeof(double) * (size_t)p->B * p->K * kRefitSplit * 5);
     L.total = off;
     return L;
 }
@@ -1622,18 +1677,14 @@ PVV_EXPORT size_t pvv_workspace_bytes(const pvv_problem *p)
 static int finish_v3(const pvv_problem *p, const Layout &L, char *ws, float *d_out, int32_t *d_win_counts,
                      int32_t *d_tn, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_select_refit, dim3(p->K, p->B), dim3(kBlock), 0, st,
+    hipLaunchKernelGGL(k_select_refit, dim3(p->K * kRefitSplit, p->B), dim3(kBlock), 0, st,
                        (const int *)(ws + L.tn), (const float2 *)(ws + L.coords),
                        (const float2 *)(ws + L.dirs), (const float2 *)(ws + L.hyps),
-                       (const int *)(ws + L.counts), (double *)(ws + L.sums),
-                       (int *)(ws + L.singular), (float2 *)(ws + L.pts), d_win_counts, p->K, p->hn,
+                       (const int *)(ws + L.counts), (double *)(ws + L.sums), d_win_counts, p->K, p->hn,
                        p->cap, p->inlier_thresh);
     if (int e = check_launch("k_select_refit")) return e;
-    const int n = p->B * p->K;
-    hipLaunchKernelGGL(k_finalize_v3, dim3((n + 255) / 256), dim3(256), 0, st,
-                       (const int *)(ws + L.tn), (const double *)(ws + L.sums),
-                       (const int *)(ws + L.singular), (const float2 *)(ws + L.pts),
-                       (float2 *)d_out, p->B, p->K, p->singular_policy);
+    hipLaunchKernelGGL(k_finalize_v3, dim3(p->B), dim3(64), 0, st, (const int *)(ws + L.tn),
+                       (const double *)(ws + L.sums), (float2 *)d_out, p->K, p->singular_policy);
     if (int e = check_launch("k_finalize_v3")) return e;
     if (d_tn) {
         hipError_t e = hipMemcpyAsync(d_tn, ws + L.tn, sizeof(int) * p->B, hipMemcpyDeviceToDevice, st);
