@@ -816,6 +816,7 @@ struct Bf16Consts {
     float eps_c;   // absolute half-width per pixel of block extent C1
     float eps0;    // absolute floor (covers the exact path's norm2 < 1e-6 reject)
     float kappa;
+    float beta2;   // band of the second-level (f32, un-translated) test used on flagged evaluations
 };
 
 // x = p[0] + p[1] + p[2] + r, |r| <= 2^-27 |x|; every piece is a bf16 value (round to nearest even)
@@ -895,8 +896,8 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
                 if (!lt_1e6(norm1) && norm1 < INFINITY && norm1 == norm1) {
                     const float ux = d.x / norm1, uy = d.y / norm1;
                     const float bx = -fc.kappa * uy, by = fc.kappa * ux;
-                    fa = make_float4(ux, uy, -(cx * ux + cy * uy), 0.f);
-                    fb = make_float4(bx, by, -(cx * bx + cy * by), 0.f);
+                    fa = make_float4(ux, uy, -(cx * ux + cy * uy), cx);   // .w: c' (for the second-level test)
+                    fb = make_float4(bx, by, -(cx * bx + cy * by), cy);
                 }
             }
             sP[pl * 2] = fa;
@@ -1005,14 +1006,28 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
                         const float t = acc[e] - fabsf(acc[8 + e]);
                         const float z = __builtin_fmaf(-fc.beta, acc[e], fabsf(t));
                         if (!__any(z <= eps)) continue;
-                        const int p = p0 + j * 16 + ebase + (e & 3) + 8 * (e >> 2);
+                        const int prow = j * 16 + ebase + (e & 3) + 8 * (e >> 2);
+                        const int p = p0 + prow;
                         const int fast = (__float_as_uint(t) >> 31) ? 0 : 1;
-                        int exact = 0;
-                        if (p < tn) {
-                            const float2 c = crd[p], d = dir_k[p];
-                            exact = vote_exact(c.x, c.y, hp.x, hp.y, d.x, d.y, thresh) ? 1 : 0;
+                        // second level: the sqrt/divide-free test of k_count_fast on d = fl(h - c) (the exact path's own
+                        // d) with the f32 unit normal from LDS; its band (beta2, eps0) is ~10x narrower than the MFMA's
+                        const float4 ra = sP[(wave * kBfPixPerWave + prow) * 2], rb = sP[(wave * kBfPixPerWave + prow) * 2 + 1];
+                        const float dx = hp.x - (ra.w + org.x), dy = hp.y - (rb.w + org.y);
+                        const float a2 = __builtin_fmaf(dx, ra.x, dy * ra.y);
+                        const float b2 = __builtin_fmaf(dx, rb.x, dy * rb.y);
+                        const float t2 = a2 - fabsf(b2);
+                        int decided = t2 > 0.f ? 1 : 0;
+                        const bool unsure = !(__builtin_fmaf(-fc.beta2, a2, fabsf(t2)) > fc.eps0) || ra.z <= -1e29f;
+                        if (__any(unsure)) {
+                            int exact = 0;
+                            if (p < tn) {
+                                const float2 c = crd[p], d = dir_k[p];
+                                exact = vote_exact(c.x, c.y, hp.x, hp.y, d.x, d.y, thresh) ? 1 : 0;
+                            }
+                            if (unsure) decided = exact;
                         }
-                        inl += exact - fast;
+                        if (p >= tn) decided = 0;
+                        inl += decided - fast;
                     }
                 }
                 if (inl) atomicAdd(&sCnt[ht * 32 + col], inl);    // LDS: 2 lanes x 4 waves per hypothesis
@@ -1478,6 +1493,8 @@ Bf16Consts bf16_consts(float thresh)
     fc.eps_c = (float)(1.25 * (1.0 + kappa) * 34.0 * u);
     fc.eps0 = (float)(1.5e-6 * (1.0 + kappa));
     fc.kappa = (float)kappa;
+    // second level: d exact-path's own, nh/B computed in f32 (<= 2u / 3u relative), one fma each => 6u(1+kappa)|d|
+    fc.beta2 = (float)(1.25 * (6.0 * (1.0 + kappa) + 8.0 / s2) * u / T);
     // PVV_DEBUG_BAND_SCALE (timing experiments only; != 1 voids the exactness guarantee): scales the guard band
     static const char *dbg = getenv("PVV_DEBUG_BAND_SCALE");
     if (dbg && *dbg) {
