@@ -47,10 +47,11 @@ def _run(cmd, verbose):
 def build_lib(force=False, verbose=False):
     src = os.path.join(CSRC, "pvnet_vote.hip")
     hdr = os.path.join(INCLUDE, "pvnet_vote.h")
-    if not force and _newer(LIB, src, hdr):
+    parts = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hpp")]
+    if not force and _newer(LIB, src, hdr, *parts):
         return LIB
     hipcc = shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
-    _run([hipcc, *HIPCC_FLAGS, "-I" + INCLUDE, "-o", LIB, src], verbose)
+    _run([hipcc, *HIPCC_FLAGS, "-I" + INCLUDE, "-I" + CSRC, "-o", LIB, src], verbose)
     return LIB
 
 

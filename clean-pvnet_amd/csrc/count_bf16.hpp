@@ -1,0 +1,270 @@
+// count_bf16.hpp -- stage 3: split-bf16 matrix-core prefilter inlier-count kernel (default).
+// Part of the single translation unit pvnet_vote.hip (included inside its anonymous namespace); see that file
+// for the numerical contract and the reference citations (K = ransac_voting_kernel.cu, P = ransac_voting_gpu.py).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// Stage 3, matrix-core prefilter form (k_count_bf16).
+//
+// k_count_fast is bound by VALU issue (7.35 VALU instructions per evaluation, 84 % VALU busy); 4 of the 6.5
+// useful ones are the two dot products a = d.nh and b' = kappa d x nh.  Those are bilinear in (hx,hy,1) and the
+// pixel's (nh, -c.nh) / (B, -c.B): a rank-3 form.  The f32 MFMA shares the fp32 VALU datapath on gfx950
+// (tools/microbench/mfma_valu_overlap.hip: no overlap), but the bf16 matrix core is a separate pipe that does
+// overlap (tools/microbench/bf16_mfma_overlap.hip).  So every fp32 operand is split EXACTLY into three bf16
+// pieces x = x0 + x1 + x2 (+ <= 2^-27 |x|), the six leading piece products of hx*nhx and of hy*nhy plus the three
+// pieces of the constant are the 15 terms of a K=16 dot product, and ONE v_mfma_f32_32x32x16_bf16 delivers a
+// (rows 0-15) and b' (rows 16-31) for 16 pixels x 32 hypotheses.  The VALU keeps t = a - |b'|, the sign-bit
+// queue and the guard-band measure: 29 instructions per 512 evaluations instead of 56 x 4.
+//
+// The MFMA result is only a PREFILTER: the decision is taken from it when |t| - beta*a > eps, otherwise that
+// evaluation is redone with the exact binary32 sequence (K:100-125).  Bound, with u = 2^-24, d = fl(h-c) as the
+// exact path sees it, o = the block's integer origin, c' = c-o (exact), h' = fl(h-o), C1 = max |c'|_1 of the block:
+//     piece residuals and dropped piece products          <= 0.5 u S,   S = |hx' nhx| + |hy' nhy| + |c'.nh|
+//     bf16 MFMA accumulation (products exact in f32; 15 f32 roundings in any order)  <= 15 u S
+//     (measured on MI355X: 3.9 u S including the split, bf16_mfma_overlap.hip)
+//     fl(h-o), the exact path's fl(h-c), f32 unit normal (3u), f32 c'.nh                 
+//  => |a_mfma - a_true| <= u (30 |d| + 34 C1),  kappa times that for b', and
+//     beta = 1.25 (30 (1+kappa) + 8/(1-T^2)) u / T,     eps = 1.25 (1+kappa) 34 u C1 + eps_abs.
+// Inlier counts stay bit-exact (tests/test_gpu_parity.py, every parity test runs through this kernel by default).
+//
+// Layout (MI355X_MICROARCH / verified in the microbenchmark): A operand lane l = row l%32, k = 8*(l/32)..+7;
+// B operand lane l = column l%32, same k; D register r of lane l = row 4*(l/32) + r%4 + 8*(r/4), column l%32.
+// Rows = (form, pixel) of a 16-pixel tile, columns = 32 hypotheses: every lane owns ONE hypothesis and 8 of the
+// 16 pixels; lanes l and l^32 share a hypothesis and are merged in LDS.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr int kBfPixPerWave = 128;   // 8 tiles of 16 pixels, A operands live in 32 VGPRs
+constexpr int kBfMaxHt = 16;         // 32-hypothesis tiles per work item (512 hypotheses)
+
+struct Bf16Consts {
+    float beta;    // relative half-width of the guard band (units of a)
+    float eps_c;   // absolute half-width per pixel of block extent C1
+    float eps0;    // absolute floor (covers the exact path's norm2 < 1e-6 reject)
+    float kappa;
+    float beta2;   // band of the second-level (f32, un-translated) test used on flagged evaluations
+};
+
+// x = p[0] + p[1] + p[2] + r, |r| <= 2^-27 |x|; every piece is a bf16 value (round to nearest even)
+__device__ __forceinline__ void split3(float x, __bf16 (&p)[3])
+{
+    p[0] = (__bf16)x;
+    float r = x - (float)p[0];
+    p[1] = (__bf16)r;
+    r = r - (float)p[1];
+    p[2] = (__bf16)r;
+}
+
+__global__ __launch_bounds__(kBlock) void k_count_bf16(
+    const float2 *__restrict__ coords /*[B,cap]*/, const float2 *__restrict__ dirs /*[B,K,cap]*/,
+    const float2 *__restrict__ hyps /*[B,K,hn]*/, int *__restrict__ counts /*[B,K,hn]*/,
+    const int *__restrict__ tn_arr, int B, int K, int hn, int cap, float thresh, Bf16Consts fc, int target_items)
+{
+    __shared__ int item_end[kMaxBatchLds];
+    __shared__ int s_htpi;
+    __shared__ bf16x8 sB[kBfMaxHt * 64];            // B operands of the item's hypothesis tiles (16 KB)
+    __shared__ float4 sP[4 * kBfPixPerWave * 2];    // per pixel: (nhx, nhy, cn', -) and (Bx, By, cB', -)  (16 KB)
+    __shared__ int sCnt[kBfMaxHt * 32];
+    __shared__ float sRed[4];
+    const int lane = lane_id(), wave = wave_id();
+    constexpr int PC = 4 * kBfPixPerWave;
+    const int nt = (hn + 31) >> 5;                  // 32-hypothesis tiles per keypoint
+
+    // hypothesis tiles per work item: up to 16, fewer when the batch is too small to fill the chip
+    if (wave == 0) {
+        long long chunks = 0;
+        for (int b = lane; b < B; b += 64) chunks += (tn_arr[b] + PC - 1) / PC;
+        chunks = wave_sum(chunks) * K;
+        int htpi = min(nt, kBfMaxHt);
+        while (htpi > 2 && chunks * ((nt + htpi - 1) / htpi) < target_items) htpi = (htpi + 1) >> 1;
+        if (lane == 0) s_htpi = htpi;
+    }
+    __syncthreads();
+    const int htpi = __builtin_amdgcn_readfirstlane(s_htpi);
+    const int nhg = (nt + htpi - 1) / htpi;
+    const int per_chunk = K * nhg;
+
+    const int total = build_item_table(item_end, tn_arr, 0, B, PC, per_chunk);
+    const int col = lane & 31, kslice = lane >> 5;
+
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        int local;
+        const int b = locate_item(item_end, B, item, &local);
+        const int chunk = local / per_chunk;
+        const int rem = local - chunk * per_chunk;
+        const int vi = rem / nhg;
+        const int hg = rem - vi * nhg;
+        const int tn = __builtin_amdgcn_readfirstlane(tn_arr[b]);
+        const int bk = b * K + vi;
+        const int ht0 = hg * htpi;
+        const int nht = min(nt, ht0 + htpi) - ht0;
+        const float2 *hyp_k = hyps + (size_t)bk * hn;
+        const float2 *crd = coords + (size_t)b * cap;
+        const float2 *dir_k = dirs + (size_t)bk * cap;
+        const int pb = chunk * PC;                              // first pixel of the block's chunk (< tn)
+
+        __syncthreads();                                        // previous item's LDS fully consumed
+        const float2 org = crd[pb];                             // integer origin: the chunk's first pixel
+
+        // ---- per-pixel operands (two pixels per thread): unit normal, its kappa-scaled perpendicular, and the
+        //      constants -(c-o).nh, -(c-o).B; a pixel the exact test can never accept (K:121 norm1 < 1e-6, a
+        //      non-finite norm1) or beyond tn gets nh = B = 0, constant -1e30: a = -1e30, b' = 0, t < 0.
+        float c1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pl = threadIdx.x + q * kBlock, p = pb + pl;
+            float4 fa = make_float4(0.f, 0.f, -1e30f, 0.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < tn) {
+                const float2 c = crd[p], d = dir_k[p];
+                const float cx = c.x - org.x, cy = c.y - org.y;  // exact (integers)
+                c1 = fmaxf(c1, fabsf(cx) + fabsf(cy));
+                const float norm1 = sqrtf(d.x * d.x + d.y * d.y);
+                if (!lt_1e6(norm1) && norm1 < INFINITY && norm1 == norm1) {
+                    const float ux = d.x / norm1, uy = d.y / norm1;
+                    const float bx = -fc.kappa * uy, by = fc.kappa * ux;
+                    fa = make_float4(ux, uy, -(cx * ux + cy * uy), cx);   // .w: c' (for the second-level test)
+                    fb = make_float4(bx, by, -(cx * bx + cy * by), cy);
+                }
+            }
+            sP[pl * 2] = fa;
+            sP[pl * 2 + 1] = fb;
+        }
+        // ---- B operands: lane l of tile ht holds column l%32, k = 8*(l/32)..+7 of
+        //      (qx0,qx1,qx2,qx0,qx1,qx0, qy0,qy1 | qy2,qy0,qy1,qy0, 1,1,1,0),  q = pieces of h' = fl(h - o)
+        int far = 0;
+        for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
+            const int h = (ht0 + (i >> 5)) * 32 + (i & 31);
+            float2 hp = make_float2(0.f, 0.f);
+            if (h < hn) hp = hyp_k[h];
+            far |= !(fabsf(hp.x) < 1e15f && fabsf(hp.y) < 1e15f);
+            __bf16 qx[3], qy[3];
+            split3(hp.x - org.x, qx);
+            split3(hp.y - org.y, qy);
+            const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
+            const bf16x8 lo8 = {qx[0], qx[1], qx[2], qx[0], qx[1], qx[0], qy[0], qy[1]};
+            const bf16x8 hi8 = {qy[2], qy[0], qy[1], qy[0], one, one, one, zero};
+            sB[(i >> 5) * 64 + (i & 31)] = lo8;
+            sB[(i >> 5) * 64 + 32 + (i & 31)] = hi8;
+        }
+        for (int i = threadIdx.x; i < nht * 32; i += kBlock) sCnt[i] = 0;
+        c1 = fmaxf(c1, __shfl_xor(c1, 32, 64));
+        c1 = fmaxf(c1, __shfl_xor(c1, 16, 64));
+        c1 = fmaxf(c1, __shfl_xor(c1, 8, 64));
+        c1 = fmaxf(c1, __shfl_xor(c1, 4, 64));
+        c1 = fmaxf(c1, __shfl_xor(c1, 2, 64));
+        c1 = fmaxf(c1, __shfl_xor(c1, 1, 64));
+        if (lane == 0) sRed[wave] = c1;
+        far = __syncthreads_or(far);
+        const float C1 = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
+        const float eps = fc.eps0 + fc.eps_c * C1;
+
+        const int p0 = pb + wave * kBfPixPerWave;               // this wave's 128 pixels
+        const int npix = min(tn - p0, kBfPixPerWave);           // may be <= 0
+
+        if (__builtin_expect(far, 0)) {
+            // some hypothesis of the item is non-finite / astronomically far: exact loop (K:100-125)
+            for (int ht = 0; ht < nht; ++ht) {
+                const int h = (ht0 + ht) * 32 + col;
+                if (h >= hn) continue;
+                const float2 hp = hyp_k[h];
+                int inl = 0;
+                for (int p = p0 + kslice; p < p0 + npix; p += 2) {
+                    const float2 c = crd[p], d = dir_k[p];
+                    inl += vote_exact(c.x, c.y, hp.x, hp.y, d.x, d.y, thresh) ? 1 : 0;
+                }
+                if (inl) atomicAdd(&sCnt[ht * 32 + col], inl);
+            }
+        } else if (npix > 0) {
+            // ---- A operands: lane l = row l%32 (form = row/16, pixel = row%16), k = 8*(l/32)..+7 of
+            //      (v0,v0,v0,v1,v1,v2 of vx | vy0,vy0 || vy0,vy1,vy1,vy2 | cv0,cv1,cv2, 0)
+            bf16x8 A[8];
+            const int form = (lane >> 4) & 1, prow = lane & 15;
+            auto make_A = [&](int j) -> bf16x8 {
+                const float4 v = sP[(wave * kBfPixPerWave + j * 16 + prow) * 2 + form];
+                __bf16 vx[3], vy[3], cv[3];
+                split3(v.x, vx);
+                split3(v.y, vy);
+                split3(v.z, cv);
+                const __bf16 zero = (__bf16)0.f;
+                const bf16x8 lo8 = {vx[0], vx[0], vx[0], vx[1], vx[1], vx[2], vy[0], vy[0]};
+                const bf16x8 hi8 = {vy[0], vy[1], vy[1], vy[2], cv[0], cv[1], cv[2], zero};
+                return kslice ? hi8 : lo8;
+            };
+#pragma unroll
+            for (int j = 0; j < 8; ++j) A[j] = make_A(j);
+            const int ebase = kslice * 4;                        // this lane's pixels: ebase + e%4 + 8*(e/4)
+            const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int ht = 0; ht < nht; ++ht) {
+                const bf16x8 Bop = sB[ht * 64 + lane];
+                int inl = 0;
+                unsigned flagged = 0u;                            // wave-uniform: tiles with an evaluation in the band
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    unsigned q = 0u;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = half * 4 + jj;
+                        const float16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j], Bop, zero16, 0, 0, 0);
+                        // conservative band test per tile: min |t|  vs  beta * max a + eps  (|t| - beta a <= eps for some
+                        // evaluation implies it); the per-evaluation measure is only formed in the rare path below
+                        float tmin = INFINITY, amax = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float t = acc[e] - fabsf(acc[8 + e]);
+                            q = __builtin_amdgcn_alignbit(q, __float_as_uint(t), 31);
+                            tmin = fminf(tmin, fabsf(t));
+                            amax = fmaxf(amax, acc[e]);
+                        }
+                        flagged |= __ballot(tmin <= __builtin_fmaf(fc.beta, amax, eps)) ? (1u << j) : 0u;
+                    }
+                    inl += 32 - __popc(q);                        // 4 tiles x 8 evaluations, sign bit set = not an inlier
+                }
+                while (__builtin_expect(flagged != 0u, 0)) {
+                    // rare: tile j holds an evaluation inside the guard band.  Re-derive its operands, repeat the
+                    // MFMA (bitwise the same result) and re-decide the flagged evaluations exactly (K:100-125).
+                    const int j = __builtin_ctz(flagged);
+                    flagged &= flagged - 1;
+                    const float16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(make_A(j), Bop, zero16, 0, 0, 0);
+                    const int h = (ht0 + ht) * 32 + col;
+                    const float2 hp = h < hn ? hyp_k[h] : make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float t = acc[e] - fabsf(acc[8 + e]);
+                        const float z = __builtin_fmaf(-fc.beta, acc[e], fabsf(t));
+                        if (!__any(z <= eps)) continue;
+                        const int prow = j * 16 + ebase + (e & 3) + 8 * (e >> 2);
+                        const int p = p0 + prow;
+                        const int fast = (__float_as_uint(t) >> 31) ? 0 : 1;
+                        // second level: the sqrt/divide-free test of k_count_fast on d = fl(h - c) (the exact path's own
+                        // d) with the f32 unit normal from LDS; its band (beta2, eps0) is ~10x narrower than the MFMA's
+                        const float4 ra = sP[(wave * kBfPixPerWave + prow) * 2], rb = sP[(wave * kBfPixPerWave + prow) * 2 + 1];
+                        const float dx = hp.x - (ra.w + org.x), dy = hp.y - (rb.w + org.y);
+                        const float a2 = __builtin_fmaf(dx, ra.x, dy * ra.y);
+                        const float b2 = __builtin_fmaf(dx, rb.x, dy * rb.y);
+                        const float t2 = a2 - fabsf(b2);
+                        int decided = t2 > 0.f ? 1 : 0;
+                        const bool unsure = !(__builtin_fmaf(-fc.beta2, a2, fabsf(t2)) > fc.eps0) || ra.z <= -1e29f;
+                        if (__any(unsure)) {
+                            int exact = 0;
+                            if (p < tn) {
+                                const float2 c = crd[p], d = dir_k[p];
+                                exact = vote_exact(c.x, c.y, hp.x, hp.y, d.x, d.y, thresh) ? 1 : 0;
+                            }
+                            if (unsure) decided = exact;
+                        }
+                        if (p >= tn) decided = 0;
+                        inl += decided - fast;
+                    }
+                }
+                if (inl) atomicAdd(&sCnt[ht * 32 + col], inl);    // LDS: 2 lanes x 4 waves per hypothesis
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
+            const int h = ht0 * 32 + i;
+            const int c = sCnt[i];
+            if (h < hn && c != 0) atomicAdd(&counts[(size_t)bk * hn + h], c);
+        }
+    }
+}

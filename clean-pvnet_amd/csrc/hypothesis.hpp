@@ -1,0 +1,43 @@
+// hypothesis.hpp -- stage 2: hypothesis generation.
+// Part of the single translation unit pvnet_vote.hip (included inside its anonymous namespace); see that file
+// for the numerical contract and the reference citations (K = ransac_voting_kernel.cu, P = ransac_voting_gpu.py).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2: hypotheses (replaces random_ P:145/P:235 + generate_hypothesis K:11-86), and zeroes
+// the inlier counters of the same (b,vi,hi).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_gen_hypothesis(
+    const int32_t *__restrict__ idxs /*[B,hn,K,2] or null*/, const int *__restrict__ tn_arr,
+    const float2 *__restrict__ coords, const float2 *__restrict__ dirs, float2 *__restrict__ hyps,
+    int *__restrict__ counts, int B, int K, int hn, int cap, uint64_t seed)
+{
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (long long)B * K * hn) return;
+    const int hi = (int)(gid % hn);
+    const int vi = (int)((gid / hn) % K);
+    const int b = (int)(gid / ((long long)hn * K));
+    counts[gid] = 0;
+    const int tn = tn_arr[b];
+    if (tn <= 0) {
+        hyps[gid] = make_float2(0.f, 0.f);
+        return;
+    }
+    int t0, t1;
+    if (idxs) {
+        const int32_t *ip = idxs + (((size_t)b * hn + hi) * K + vi) * 2;
+        t0 = ip[0];
+        t1 = ip[1];
+        // the reference reads out of bounds here; clamp instead of faulting
+        t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);
+        t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
+    } else {
+        uint32_t c = (uint32_t)(hi * K + vi) * 2u;
+        t0 = (int)(rng_u32(seed, 1u, (uint32_t)b, c) % (uint32_t)tn);
+        t1 = (int)(rng_u32(seed, 1u, (uint32_t)b, c + 1u) % (uint32_t)tn);
+    }
+    const float2 *dp = dirs + ((size_t)b * K + vi) * cap;
+    const float2 *cp = coords + (size_t)b * cap;
+    float2 d0 = dp[t0], d1 = dp[t1], c0 = cp[t0], c1 = cp[t1];
+    hyps[gid] = hypothesis_exact(d0.x, d0.y, c0.x, c0.y, d1.x, d1.y, c1.x, c1.y);
+}

@@ -1,0 +1,161 @@
+// refit.hpp -- stage 4 (v3): winner selection, least-squares refit, singular policy.
+// Part of the single translation unit pvnet_vote.hip (included inside its anonymous namespace); see that file
+// for the numerical contract and the reference citations (K = ransac_voting_kernel.cu, P = ransac_voting_gpu.py).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// Stage 4 (v3): winner selection + least-squares refit (P:159-167 and P:176-196).
+// One block per (keypoint, image).
+// ---------------------------------------------------------------------------------------------
+// kRefitSplit blocks per (keypoint, image), each over a quarter of the pixels: the exact re-vote is a long
+// dependent chain (two sqrt, one divide) and 576 blocks alone leave the SIMDs latency-bound.  Partial sums go to
+// sums[b,vi,split,5] and are merged in a fixed order by k_finalize_v3 (deterministic).
+constexpr int kRefitSplit = 4;
+
+__global__ __launch_bounds__(kBlock) void k_select_refit(
+    const int *__restrict__ tn_arr, const float2 *__restrict__ coords,
+    const float2 *__restrict__ dirs, const float2 *__restrict__ hyps,
+    const int *__restrict__ counts, double *__restrict__ sums /*[B,K,kRefitSplit,5]*/,
+    int *__restrict__ win_counts /*[B,K] or null*/, int K, int hn, int cap, float thresh)
+{
+    __shared__ int s_cnt[4], s_idx[4];
+    __shared__ double red5[20];
+    const int vi = blockIdx.x / kRefitSplit, split = blockIdx.x % kRefitSplit, b = blockIdx.y;
+    const int bk = b * K + vi;
+    const int tn = tn_arr[b];
+    double *part = sums + ((size_t)bk * kRefitSplit + split) * 5;
+    if (tn <= 0) {
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < 5; ++i) part[i] = 0.0;
+            if (win_counts && split == 0) win_counts[bk] = 0;
+        }
+        return;
+    }
+    // torch.max(counts, 0): maximal count, FIRST index among ties (P:160)
+    const int *cp = counts + (size_t)bk * hn;
+    int best = -1, besti = 0x7fffffff;
+    for (int h = threadIdx.x; h < hn; h += kBlock) {
+        int c = cp[h];
+        if (c > best) { best = c; besti = h; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int oc = __shfl_xor(best, o, 64), oi = __shfl_xor(besti, o, 64);
+        if (oc > best || (oc == best && oi < besti)) { best = oc; besti = oi; }
+    }
+    if (lane_id() == 0) { s_cnt[threadIdx.x >> 6] = best; s_idx[threadIdx.x >> 6] = besti; }
+    __syncthreads();
+    best = s_cnt[0]; besti = s_idx[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (s_cnt[w] > best || (s_cnt[w] == best && s_idx[w] < besti)) { best = s_cnt[w]; besti = s_idx[w]; }
+
+    // P:162-167: all_win_ratio (0) < count/tn  <=>  count > 0; otherwise the winner stays (0,0)
+    float2 win = make_float2(0.f, 0.f);
+    if (best > 0) win = hyps[(size_t)bk * hn + besti];
+
+    // P:176-191: re-vote the winner (hn = 1) and accumulate the normal equations in binary64
+    const float2 *dp = dirs + (size_t)bk * cap;
+    const float2 *cq = coords + (size_t)b * cap;
+    double xx = 0, xy = 0, yy = 0, bx = 0, by = 0;
+    // this block's quarter of the pixels; four pixels per trip so that the loads of a trip overlap
+    const int per = (tn + kRefitSplit - 1) / kRefitSplit;
+    const int tbeg = split * per, tend = min(tn, tbeg + per);
+    for (int t0 = tbeg + threadIdx.x; t0 < tend; t0 += 4 * kBlock) {
+        float2 d[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ti = t0 + u * kBlock;
+            d[u] = ti < tend ? dp[ti] : make_float2(0.f, 0.f);  // zero direction: norm1 < 1e-6, never an inlier
+            c[u] = ti < tend ? cq[ti] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!vote_exact(c[u].x, c[u].y, win.x, win.y, d[u].x, d[u].y, thresh)) continue;
+            double nx = (double)d[u].y, ny = -(double)d[u].x;          // P:178-179
+            double bb = nx * (double)c[u].x + ny * (double)c[u].y;     // P:189
+            xx += nx * nx; xy += nx * ny; yy += ny * ny;               // P:190
+            bx += nx * bb; by += ny * bb;                              // P:191
+        }
+    }
+    // one reduction for all five sums: five independent shuffle chains interleave, a single barrier
+    double v[5] = {xx, xy, yy, bx, by};
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v[i] += __shfl_xor(v[i], o, 64);
+    }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) red5[(threadIdx.x >> 6) * 5 + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) part[threadIdx.x] = red5[threadIdx.x] + red5[5 + threadIdx.x] + red5[10 + threadIdx.x] + red5[15 + threadIdx.x];
+    if (threadIdx.x == 0 && win_counts && split == 0) win_counts[bk] = best;
+}
+
+// Merge the partial normal equations, solve the 2x2 systems (P:193, closed form in binary64) and apply the
+// singular-matrix policy across the keypoints of an image (b_inv, P:97-109).  One block per image.
+__global__ __launch_bounds__(64) void k_finalize_v3(const int *__restrict__ tn_arr, const double *__restrict__ sums,
+                                                    float2 *__restrict__ out, int K, int policy)
+{
+    __shared__ int any_singular;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) any_singular = 0;
+    __syncthreads();
+    const bool skipped = tn_arr[b] <= 0;
+    for (int v0 = 0; v0 < K; v0 += 64) {          // K <= 64 in every real use: one trip
+        const int vi = v0 + threadIdx.x;
+        float2 o = make_float2(0.f, 0.f);
+        double bx = 0, by = 0;
+        bool sing = false;
+        if (vi < K && !skipped) {
+            const double *q = sums + ((size_t)b * K + vi) * kRefitSplit * 5;
+            double xx = 0, xy = 0, yy = 0;
+            for (int sp = 0; sp < kRefitSplit; ++sp) {
+                xx += q[sp * 5]; xy += q[sp * 5 + 1]; yy += q[sp * 5 + 2]; bx += q[sp * 5 + 3]; by += q[sp * 5 + 4];
+            }
+            const double det = xx * yy - xy * xy;
+            sing = !(det != 0.0) || !isfinite(det);
+            if (!sing) {
+                o.x = (float)((yy * bx - xy * by) / det);
+                o.y = (float)((xx * by - xy * bx) / det);
+            }
+        }
+        if (K > 64) {   // generic path: the policy needs every keypoint's flag first
+            if (sing) atomicOr(&any_singular, 1);
+            continue;
+        }
+        if (sing) any_singular = 1;
+        __syncthreads();
+        if (vi < K) {
+            if (!skipped && any_singular && policy != PVV_SINGULAR_ZERO) {
+                if (policy == PVV_SINGULAR_REFERENCE) o = make_float2((float)bx, (float)by);   // inverse := identity => x = ATb
+                else o = make_float2(0.f, 0.f);                                                // v1: the whole image becomes zeros
+            }
+            out[(size_t)b * K + vi] = o;
+        }
+        return;
+    }
+    // K > 64: second pass now that any_singular is complete
+    __syncthreads();
+    for (int vi = threadIdx.x; vi < K; vi += 64) {
+        float2 o = make_float2(0.f, 0.f);
+        if (!skipped) {
+            const double *q = sums + ((size_t)b * K + vi) * kRefitSplit * 5;
+            double xx = 0, xy = 0, yy = 0, bx = 0, by = 0;
+            for (int sp = 0; sp < kRefitSplit; ++sp) {
+                xx += q[sp * 5]; xy += q[sp * 5 + 1]; yy += q[sp * 5 + 2]; bx += q[sp * 5 + 3]; by += q[sp * 5 + 4];
+            }
+            const double det = xx * yy - xy * xy;
+            const bool sing = !(det != 0.0) || !isfinite(det);
+            if (!sing) {
+                o.x = (float)((yy * bx - xy * by) / det);
+                o.y = (float)((xx * by - xy * bx) / det);
+            }
+            if (any_singular && policy != PVV_SINGULAR_ZERO)
+                o = policy == PVV_SINGULAR_REFERENCE ? make_float2((float)bx, (float)by) : make_float2(0.f, 0.f);
+        }
+        out[(size_t)b * K + vi] = o;
+    }
+}
