@@ -122,16 +122,20 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events on the launch stream around re-launches ----
         _o, win, tn, ws = ext.ransac_voting_v3(mask, vertex, hn, thresh, 5, 30000, None, None, 1, ext.SINGULAR_REFERENCE)
-        reps = 20
+        # groups of back-to-back re-launches between one event pair each: the host's launch latency is hidden behind
+        # the previous launch, so the figure is the kernel's duration (plus the ~1.5 us kernel boundary), which is
+        # what rocprofv3 --kernel-trace reports for it
+        groups, per_group = 5, 10
         for _ in range(3):
             ext.rerun_count_kernel(mask, vertex, hn, thresh, 5, 30000, ws, False)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(groups)]
         for a, b in evs:
             a.record()
-            ext.rerun_count_kernel(mask, vertex, hn, thresh, 5, 30000, ws, False)
+            for _ in range(per_group):
+                ext.rerun_count_kernel(mask, vertex, hn, thresh, 5, 30000, ws, False)
             b.record()
         torch.cuda.synchronize()
-        k_ms = sorted(a.elapsed_time(b) for a, b in evs)
+        k_ms = sorted(a.elapsed_time(b) / per_group for a, b in evs)
         k_avg_ms = sum(k_ms) / len(k_ms)
         alg_bytes = synth.dense_field_bytes(B, H, W, K, hn)
         achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
