@@ -23,8 +23,9 @@
 //     bf16 MFMA accumulation (products exact in f32; 15 f32 roundings in any order)  <= 15 u S
 //     (measured on MI355X: 3.9 u S including the split, bf16_mfma_overlap.hip)
 //     fl(h-o), the exact path's fl(h-c), f32 unit normal (3u), f32 c'.nh                 
-//  => |a_mfma - a_true| <= u (30 |d| + 34 C1),  kappa times that for b', and
-//     beta = 1.25 (30 (1+kappa) + 8/(1-T^2)) u / T,     eps = 1.25 (1+kappa) 34 u C1 + eps_abs.
+//  => |a_mfma - a_true| <= u (30 |d| + 34 C1);  for b' the operand B = kappa perp(nh) carries 5u instead of 3u:
+//     kappa u (32 |d| + 34 C1);
+//     beta = 1.25 (32 (1+kappa) + 8/(1-T^2)) u / T,     eps = 1.25 (1+kappa) 34 u C1 + eps_abs.
 // Inlier counts stay bit-exact (tests/test_gpu_parity.py, every parity test runs through this kernel by default).
 //
 // Layout (MI355X_MICROARCH / verified in the microbenchmark): A operand lane l = row l%32, k = 8*(l/32)..+7;

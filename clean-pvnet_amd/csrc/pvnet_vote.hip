@@ -168,7 +168,7 @@ Bf16Consts bf16_consts(float thresh)
     const double T = (double)thresh, s2 = 1.0 - T * T, kappa = T / std::sqrt(s2);
     const double u = 0x1p-24;
     Bf16Consts fc;
-    fc.beta = (float)(1.25 * (30.0 * (1.0 + kappa) + 8.0 / s2) * u / T);
+    fc.beta = (float)(1.25 * (32.0 * (1.0 + kappa) + 8.0 / s2) * u / T);
     fc.eps_c = (float)(1.25 * (1.0 + kappa) * 34.0 * u);
     fc.eps0 = (float)(1.5e-6 * (1.0 + kappa));
     fc.kappa = (float)kappa;

@@ -85,14 +85,14 @@ def test_split_bf16_prefilter_band(T):
     bf16_consts.  C1 = the block extent."""
     n = 1_000_000
     Td0 = np.float64(f32(T)); s20 = 1 - Td0 * Td0; k0 = Td0 / np.sqrt(s20)
-    beta0 = 1.25 * (30 * (1 + k0) + 8 / s20) * U / Td0
+    beta0 = 1.25 * (32 * (1 + k0) + 8 / s20) * U / Td0
     cx, cy, hx, hy, nx, ny = samples(n, T, 12, spread=5 * beta0 * Td0 * np.sqrt(s20) / np.arccos(Td0))
     rng = np.random.RandomState(5)
     ox = (cx - rng.randint(0, 120, n)).astype(f32)                         # block origin: within ~120 px, integer
     oy = (cy - rng.randint(0, 4, n)).astype(f32)
     C1 = f32(124.0)
     Td = np.float64(f32(T)); s2 = 1 - Td * Td; kappa = Td / np.sqrt(s2)
-    beta = f32(1.25 * (30 * (1 + kappa) + 8 / s2) * U / Td)
+    beta = f32(1.25 * (32 * (1 + kappa) + 8 / s2) * U / Td)
     eps = f32(1.25 * (1 + kappa) * 34 * U) * C1 + f32(1.5e-6 * (1 + kappa))
     kf = f32(kappa)
     norm1 = np.sqrt(nx * nx + ny * ny)
