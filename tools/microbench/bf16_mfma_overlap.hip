@@ -85,10 +85,20 @@ int main()
     double worst = 0, worst_rel_u = 0;
     __bf16 *dA, *dB; float *dD;
     (void)hipMalloc(&dA, 32 * 16 * 2); (void)hipMalloc(&dB, 16 * 32 * 2); (void)hipMalloc(&dD, 32 * 32 * 4);
-    for (int trial = 0; trial < 200; ++trial) {
-        for (int j = 0; j < 32; ++j) { hx[j] = U(rng) * 400; hy[j] = U(rng) * 300; }
-        for (int i = 0; i < 32; ++i) { float t = U(rng) * 3.14159f; nx[i] = cosf(t); ny[i] = sinf(t); cn[i] = U(rng) * 500; }
-        // rows = pixels (A), cols = hyps (B).  term order k: (nx_i*hx_j : i+j<=4) x6, same for y x6, cn pieces x3, pad
+    for (int scenario = 0; scenario < 3; ++scenario) {
+    worst = 0; worst_rel_u = 0;
+    for (int trial = 0; trial < 400; ++trial) {
+        // scenario 0: independent magnitudes; 1: heavy cancellation (hypothesis ~1 px from the pixel, both hundreds of
+        // px from the origin: a = (h'-c').n is tiny against its terms); 2: terms spread over 8 orders of magnitude
+        for (int i = 0; i < 32; ++i) { float t = U(rng) * 3.14159f; nx[i] = cosf(t); ny[i] = sinf(t); }
+        std::vector<float> pcx(32), pcy(32);
+        for (int i = 0; i < 32; ++i) { pcx[i] = floorf(U(rng) * 400); pcy[i] = floorf(U(rng) * 300); }
+        for (int j = 0; j < 32; ++j) {
+            if (scenario == 0) { hx[j] = U(rng) * 400; hy[j] = U(rng) * 300; }
+            else if (scenario == 1) { hx[j] = pcx[j] + U(rng) * 1.5f; hy[j] = pcy[j] + U(rng) * 1.5f; }
+            else { hx[j] = U(rng) * powf(10.f, U(rng) * 4); hy[j] = U(rng) * powf(10.f, U(rng) * 4); }
+        }
+        for (int i = 0; i < 32; ++i) cn[i] = -(pcx[i] * nx[i] + pcy[i] * ny[i]);
         static const int PI[6] = {0, 0, 0, 1, 1, 2}, PJ[6] = {0, 1, 2, 0, 1, 0};
         for (int i = 0; i < 32; ++i) {
             float px[3], py[3], pc[3]; split3(nx[i], px); split3(ny[i], py); split3(cn[i], pc);
@@ -112,9 +122,10 @@ int main()
             double sc = fabs((double)hx[j] * nx[i]) + fabs((double)hy[j] * ny[i]) + fabs((double)cn[i]);
             double err = fabs((double)D[i * 32 + j] - ex);
             if (err > worst) worst = err;
-            if (err / sc / 5.96e-8 > worst_rel_u) worst_rel_u = err / sc / 5.96e-8;
+            if (sc > 0 && err / sc / 5.96e-8 > worst_rel_u) worst_rel_u = err / sc / 5.96e-8;
         }
     }
-    printf("split-bf16 MFMA dot (15 terms): worst abs err %.3g, worst err / (sum|terms| * u) = %.2f\n", worst, worst_rel_u);
+    printf("scenario %d: split-bf16 MFMA dot (15 terms): worst abs err %.3g, worst err / (sum|terms| * u) = %.2f\n", scenario, worst, worst_rel_u);
+    }
     return 0;
 }
