@@ -211,7 +211,7 @@ int launch_count_fast(const pvv_problem *p, const Layout &L, char *ws, hipStream
     // one wave walks per work item, and how many work items per CU a small batch is still split into
     static const int per_cu = env_int("PVV_GRID_PER_CU", 24);
     static const int ppw = env_int("PVV_PIX_PER_WAVE", 128);
-    static const int items_per_cu = env_int("PVV_ITEMS_PER_CU", 6);
+    static const int items_per_cu = env_int("PVV_ITEMS_PER_CU", 2);
     const int grid2 = per_cu * num_cus(), grid4 = grid2, grid8 = grid2;
     const float8v *recs = (const float8v *)(ws + L.recs);
     const float2 *hyps = (const float2 *)(ws + L.hyps);
@@ -231,7 +231,7 @@ int launch_count_fast(const pvv_problem *p, const Layout &L, char *ws, hipStream
 int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st)
 {
     static const int per_cu = env_int("PVV_GRID_PER_CU", 24);
-    static const int items_per_cu = env_int("PVV_ITEMS_PER_CU", 6);
+    static const int items_per_cu = env_int("PVV_ITEMS_PER_CU", 2);
     hipLaunchKernelGGL(k_count_bf16, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, (const float2 *)(ws + L.coords),
                        (const float2 *)(ws + L.dirs), (const float2 *)(ws + L.hyps), (int *)(ws + L.counts),
                        (const int *)(ws + L.tn), p->B, p->K, p->hn, p->cap, p->inlier_thresh,
