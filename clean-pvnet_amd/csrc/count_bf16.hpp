@@ -63,28 +63,36 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
     const int *__restrict__ tn_arr, int B, int K, int hn, int cap, float thresh, Bf16Consts fc, int target_items)
 {
     __shared__ int item_end[kMaxBatchLds];
-    __shared__ int s_htpi;
-    __shared__ bf16x8 sB[kBfMaxHt * 64];            // B operands of the item's hypothesis tiles (16 KB)
-    __shared__ float4 sP[4 * kBfPixPerWave * 2];    // per pixel: (nhx, nhy, cn', -) and (Bx, By, cB', -)  (16 KB)
+    __shared__ int s_htpi, s_gpi;
+    __shared__ bf16x8 sB[kBfMaxHt * 64];            // B operands of the current hypothesis group (16 KB)
+    __shared__ float4 sP[4 * kBfPixPerWave * 2];    // per pixel: (nhx, nhy, cn', c'x) and (Bx, By, cB', c'y)  (16 KB)
     __shared__ int sCnt[kBfMaxHt * 32];
     __shared__ float sRed[4];
     const int lane = lane_id(), wave = wave_id();
     constexpr int PC = 4 * kBfPixPerWave;
     const int nt = (hn + 31) >> 5;                  // 32-hypothesis tiles per keypoint
 
-    // hypothesis tiles per work item: up to 16, fewer when the batch is too small to fill the chip
+    // Work item = (image, keypoint, 512-pixel chunk, a run of hypothesis groups).  A group is up to 16 tiles (512
+    // hypotheses, what fits the LDS staging); an item walks as many groups as possible (the pixel operands are
+    // built once per item), fewer -- and smaller groups -- when the batch is too small to fill the chip.
     if (wave == 0) {
         long long chunks = 0;
         for (int b = lane; b < B; b += 64) chunks += (tn_arr[b] + PC - 1) / PC;
         chunks = wave_sum(chunks) * K;
         int htpi = min(nt, kBfMaxHt);
-        while (htpi > 2 && chunks * ((nt + htpi - 1) / htpi) < target_items) htpi = (htpi + 1) >> 1;
-        if (lane == 0) s_htpi = htpi;
+        int nhg = (nt + htpi - 1) / htpi;
+        int gpi = nhg;                                              // groups per item
+        while (gpi > 1 && chunks * ((nhg + gpi - 1) / gpi) < target_items) gpi = (gpi + 1) >> 1;
+        if (gpi == 1)
+            while (htpi > 2 && chunks * ((nt + htpi - 1) / htpi) < target_items) htpi = (htpi + 1) >> 1;
+        if (lane == 0) { s_htpi = htpi; s_gpi = gpi; }
     }
     __syncthreads();
     const int htpi = __builtin_amdgcn_readfirstlane(s_htpi);
-    const int nhg = (nt + htpi - 1) / htpi;
-    const int per_chunk = K * nhg;
+    const int gpi = __builtin_amdgcn_readfirstlane(s_gpi);
+    const int nhg = (nt + htpi - 1) / htpi;          // hypothesis groups per keypoint
+    const int nruns = (nhg + gpi - 1) / gpi;         // runs of groups = items per (chunk, keypoint)
+    const int per_chunk = K * nruns;
 
     const int total = build_item_table(item_end, tn_arr, 0, B, PC, per_chunk);
     const int col = lane & 31, kslice = lane >> 5;
@@ -94,12 +102,10 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
         const int b = locate_item(item_end, B, item, &local);
         const int chunk = local / per_chunk;
         const int rem = local - chunk * per_chunk;
-        const int vi = rem / nhg;
-        const int hg = rem - vi * nhg;
+        const int vi = rem / nruns;
+        const int run = rem - vi * nruns;
         const int tn = __builtin_amdgcn_readfirstlane(tn_arr[b]);
         const int bk = b * K + vi;
-        const int ht0 = hg * htpi;
-        const int nht = min(nt, ht0 + htpi) - ht0;
         const float2 *hyp_k = hyps + (size_t)bk * hn;
         const float2 *crd = coords + (size_t)b * cap;
         const float2 *dir_k = dirs + (size_t)bk * cap;
@@ -131,24 +137,6 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
             sP[pl * 2] = fa;
             sP[pl * 2 + 1] = fb;
         }
-        // ---- B operands: lane l of tile ht holds column l%32, k = 8*(l/32)..+7 of
-        //      (qx0,qx1,qx2,qx0,qx1,qx0, qy0,qy1 | qy2,qy0,qy1,qy0, 1,1,1,0),  q = pieces of h' = fl(h - o)
-        int far = 0;
-        for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
-            const int h = (ht0 + (i >> 5)) * 32 + (i & 31);
-            float2 hp = make_float2(0.f, 0.f);
-            if (h < hn) hp = hyp_k[h];
-            far |= !(fabsf(hp.x) < 1e15f && fabsf(hp.y) < 1e15f);
-            __bf16 qx[3], qy[3];
-            split3(hp.x - org.x, qx);
-            split3(hp.y - org.y, qy);
-            const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
-            const bf16x8 lo8 = {qx[0], qx[1], qx[2], qx[0], qx[1], qx[0], qy[0], qy[1]};
-            const bf16x8 hi8 = {qy[2], qy[0], qy[1], qy[0], one, one, one, zero};
-            sB[(i >> 5) * 64 + (i & 31)] = lo8;
-            sB[(i >> 5) * 64 + 32 + (i & 31)] = hi8;
-        }
-        for (int i = threadIdx.x; i < nht * 32; i += kBlock) sCnt[i] = 0;
         c1 = fmaxf(c1, __shfl_xor(c1, 32, 64));
         c1 = fmaxf(c1, __shfl_xor(c1, 16, 64));
         c1 = fmaxf(c1, __shfl_xor(c1, 8, 64));
@@ -156,116 +144,144 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
         c1 = fmaxf(c1, __shfl_xor(c1, 2, 64));
         c1 = fmaxf(c1, __shfl_xor(c1, 1, 64));
         if (lane == 0) sRed[wave] = c1;
-        far = __syncthreads_or(far);
+        __syncthreads();
         const float C1 = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
         const float eps = fc.eps0 + fc.eps_c * C1;
 
         const int p0 = pb + wave * kBfPixPerWave;               // this wave's 128 pixels
         const int npix = min(tn - p0, kBfPixPerWave);           // may be <= 0
 
-        if (__builtin_expect(far, 0)) {
-            // some hypothesis of the item is non-finite / astronomically far: exact loop (K:100-125)
-            for (int ht = 0; ht < nht; ++ht) {
-                const int h = (ht0 + ht) * 32 + col;
-                if (h >= hn) continue;
-                const float2 hp = hyp_k[h];
-                int inl = 0;
-                for (int p = p0 + kslice; p < p0 + npix; p += 2) {
-                    const float2 c = crd[p], d = dir_k[p];
-                    inl += vote_exact(c.x, c.y, hp.x, hp.y, d.x, d.y, thresh) ? 1 : 0;
-                }
-                if (inl) atomicAdd(&sCnt[ht * 32 + col], inl);
-            }
-        } else if (npix > 0) {
-            // ---- A operands: lane l = row l%32 (form = row/16, pixel = row%16), k = 8*(l/32)..+7 of
-            //      (v0,v0,v0,v1,v1,v2 of vx | vy0,vy0 || vy0,vy1,vy1,vy2 | cv0,cv1,cv2, 0)
-            bf16x8 A[8];
-            const int form = (lane >> 4) & 1, prow = lane & 15;
-            auto make_A = [&](int j) -> bf16x8 {
-                const float4 v = sP[(wave * kBfPixPerWave + j * 16 + prow) * 2 + form];
-                __bf16 vx[3], vy[3], cv[3];
-                split3(v.x, vx);
-                split3(v.y, vy);
-                split3(v.z, cv);
-                const __bf16 zero = (__bf16)0.f;
-                const bf16x8 lo8 = {vx[0], vx[0], vx[0], vx[1], vx[1], vx[2], vy[0], vy[0]};
-                const bf16x8 hi8 = {vy[0], vy[1], vy[1], vy[2], cv[0], cv[1], cv[2], zero};
-                return kslice ? hi8 : lo8;
-            };
+        // ---- A operands: lane l = row l%32 (form = row/16, pixel = row%16), k = 8*(l/32)..+7 of
+        //      (v0,v0,v0,v1,v1,v2 of vx | vy0,vy0 || vy0,vy1,vy1,vy2 | cv0,cv1,cv2, 0); built once per item
+        bf16x8 A[8];
+        const int form = (lane >> 4) & 1, prow = lane & 15;
+        auto make_A = [&](int j) -> bf16x8 {
+            const float4 v = sP[(wave * kBfPixPerWave + j * 16 + prow) * 2 + form];
+            __bf16 vx[3], vy[3], cv[3];
+            split3(v.x, vx);
+            split3(v.y, vy);
+            split3(v.z, cv);
+            const __bf16 zero = (__bf16)0.f;
+            const bf16x8 lo8 = {vx[0], vx[0], vx[0], vx[1], vx[1], vx[2], vy[0], vy[0]};
+            const bf16x8 hi8 = {vy[0], vy[1], vy[1], vy[2], cv[0], cv[1], cv[2], zero};
+            return kslice ? hi8 : lo8;
+        };
+        if (npix > 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) A[j] = make_A(j);
-            const int ebase = kslice * 4;                        // this lane's pixels: ebase + e%4 + 8*(e/4)
-            const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int ht = 0; ht < nht; ++ht) {
-                const bf16x8 Bop = sB[ht * 64 + lane];
-                int inl = 0;
-                unsigned flagged = 0u;                            // wave-uniform: tiles with an evaluation in the band
+        }
+        const int ebase = kslice * 4;                            // this lane's pixels: ebase + e%4 + 8*(e/4)
+        const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+        const int g0 = run * gpi, g1 = min(nhg, g0 + gpi);
+        for (int g = g0; g < g1; ++g) {
+            const int ht0 = g * htpi;
+            const int nht = min(nt, ht0 + htpi) - ht0;
+            // ---- B operands of this group: lane l of tile ht holds column l%32, k = 8*(l/32)..+7 of
+            //      (qx0,qx1,qx2,qx0,qx1,qx0, qy0,qy1 | qy2,qy0,qy1,qy0, 1,1,1,0),  q = pieces of h' = fl(h - o)
+            int far = 0;
+            for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
+                const int h = (ht0 + (i >> 5)) * 32 + (i & 31);
+                float2 hp = make_float2(0.f, 0.f);
+                if (h < hn) hp = hyp_k[h];
+                far |= !(fabsf(hp.x) < 1e15f && fabsf(hp.y) < 1e15f);
+                __bf16 qx[3], qy[3];
+                split3(hp.x - org.x, qx);
+                split3(hp.y - org.y, qy);
+                const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
+                const bf16x8 lo8 = {qx[0], qx[1], qx[2], qx[0], qx[1], qx[0], qy[0], qy[1]};
+                const bf16x8 hi8 = {qy[2], qy[0], qy[1], qy[0], one, one, one, zero};
+                sB[(i >> 5) * 64 + (i & 31)] = lo8;
+                sB[(i >> 5) * 64 + 32 + (i & 31)] = hi8;
+                sCnt[i] = 0;        // zeroed and (below) flushed by the same thread
+            }
+            far = __syncthreads_or(far);
+
+            if (__builtin_expect(far, 0)) {
+                // some hypothesis of the group is non-finite / astronomically far: exact loop (K:100-125)
+                for (int ht = 0; ht < nht; ++ht) {
+                    const int h = (ht0 + ht) * 32 + col;
+                    if (h >= hn) continue;
+                    const float2 hp = hyp_k[h];
+                    int inl = 0;
+                    for (int p = p0 + kslice; p < p0 + npix; p += 2) {
+                        const float2 c = crd[p], d = dir_k[p];
+                        inl += vote_exact(c.x, c.y, hp.x, hp.y, d.x, d.y, thresh) ? 1 : 0;
+                    }
+                    if (inl) atomicAdd(&sCnt[ht * 32 + col], inl);
+                }
+            } else if (npix > 0) {
+                for (int ht = 0; ht < nht; ++ht) {
+                    const bf16x8 Bop = sB[ht * 64 + lane];
+                    int inl = 0;
+                    unsigned flagged = 0u;                            // wave-uniform: tiles with an evaluation in the band
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    unsigned q = 0u;
+                    for (int half = 0; half < 2; ++half) {
+                        unsigned q = 0u;
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const int j = half * 4 + jj;
-                        const float16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j], Bop, zero16, 0, 0, 0);
-                        // conservative band test per tile: min |t|  vs  beta * max a + eps  (|t| - beta a <= eps for some
-                        // evaluation implies it); the per-evaluation measure is only formed in the rare path below
-                        float tmin = INFINITY, amax = 0.f;
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int j = half * 4 + jj;
+                            const float16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j], Bop, zero16, 0, 0, 0);
+                            // conservative band test per tile: min |t|  vs  beta * max a + eps  (|t| - beta a <= eps for some
+                            // evaluation implies it); the per-evaluation measure is only formed in the rare path below
+                            float tmin = INFINITY, amax = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float t = acc[e] - fabsf(acc[8 + e]);
+                                q = __builtin_amdgcn_alignbit(q, __float_as_uint(t), 31);
+                                tmin = fminf(tmin, fabsf(t));
+                                amax = fmaxf(amax, acc[e]);
+                            }
+                            flagged |= __ballot(tmin <= __builtin_fmaf(fc.beta, amax, eps)) ? (1u << j) : 0u;
+                        }
+                        inl += 32 - __popc(q);                        // 4 tiles x 8 evaluations, sign bit set = not an inlier
+                    }
+                    while (__builtin_expect(flagged != 0u, 0)) {
+                        // rare: tile j holds an evaluation inside the guard band.  Re-derive its operands, repeat the
+                        // MFMA (bitwise the same result) and re-decide the flagged evaluations exactly (K:100-125).
+                        const int j = __builtin_ctz(flagged);
+                        flagged &= flagged - 1;
+                        const float16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(make_A(j), Bop, zero16, 0, 0, 0);
+                        const int h = (ht0 + ht) * 32 + col;
+                        const float2 hp = h < hn ? hyp_k[h] : make_float2(0.f, 0.f);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float t = acc[e] - fabsf(acc[8 + e]);
-                            q = __builtin_amdgcn_alignbit(q, __float_as_uint(t), 31);
-                            tmin = fminf(tmin, fabsf(t));
-                            amax = fmaxf(amax, acc[e]);
-                        }
-                        flagged |= __ballot(tmin <= __builtin_fmaf(fc.beta, amax, eps)) ? (1u << j) : 0u;
-                    }
-                    inl += 32 - __popc(q);                        // 4 tiles x 8 evaluations, sign bit set = not an inlier
-                }
-                while (__builtin_expect(flagged != 0u, 0)) {
-                    // rare: tile j holds an evaluation inside the guard band.  Re-derive its operands, repeat the
-                    // MFMA (bitwise the same result) and re-decide the flagged evaluations exactly (K:100-125).
-                    const int j = __builtin_ctz(flagged);
-                    flagged &= flagged - 1;
-                    const float16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(make_A(j), Bop, zero16, 0, 0, 0);
-                    const int h = (ht0 + ht) * 32 + col;
-                    const float2 hp = h < hn ? hyp_k[h] : make_float2(0.f, 0.f);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float t = acc[e] - fabsf(acc[8 + e]);
-                        const float z = __builtin_fmaf(-fc.beta, acc[e], fabsf(t));
-                        if (!__any(z <= eps)) continue;
-                        const int prow = j * 16 + ebase + (e & 3) + 8 * (e >> 2);
-                        const int p = p0 + prow;
-                        const int fast = (__float_as_uint(t) >> 31) ? 0 : 1;
-                        // second level: the sqrt/divide-free test of k_count_fast on d = fl(h - c) (the exact path's own
-                        // d) with the f32 unit normal from LDS; its band (beta2, eps0) is ~10x narrower than the MFMA's
-                        const float4 ra = sP[(wave * kBfPixPerWave + prow) * 2], rb = sP[(wave * kBfPixPerWave + prow) * 2 + 1];
-                        const float dx = hp.x - (ra.w + org.x), dy = hp.y - (rb.w + org.y);
-                        const float a2 = __builtin_fmaf(dx, ra.x, dy * ra.y);
-                        const float b2 = __builtin_fmaf(dx, rb.x, dy * rb.y);
-                        const float t2 = a2 - fabsf(b2);
-                        int decided = t2 > 0.f ? 1 : 0;
-                        const bool unsure = !(__builtin_fmaf(-fc.beta2, a2, fabsf(t2)) > fc.eps0) || ra.z <= -1e29f;
-                        if (__any(unsure)) {
-                            int exact = 0;
-                            if (p < tn) {
-                                const float2 c = crd[p], d = dir_k[p];
-                                exact = vote_exact(c.x, c.y, hp.x, hp.y, d.x, d.y, thresh) ? 1 : 0;
+                            const float z = __builtin_fmaf(-fc.beta, acc[e], fabsf(t));
+                            if (!__any(z <= eps)) continue;
+                            const int prow = j * 16 + ebase + (e & 3) + 8 * (e >> 2);
+                            const int p = p0 + prow;
+                            const int fast = (__float_as_uint(t) >> 31) ? 0 : 1;
+                            // second level: the sqrt/divide-free test of k_count_fast on d = fl(h - c) (the exact path's own
+                            // d) with the f32 unit normal from LDS; its band (beta2, eps0) is ~10x narrower than the MFMA's
+                            const float4 ra = sP[(wave * kBfPixPerWave + prow) * 2], rb = sP[(wave * kBfPixPerWave + prow) * 2 + 1];
+                            const float dx = hp.x - (ra.w + org.x), dy = hp.y - (rb.w + org.y);
+                            const float a2 = __builtin_fmaf(dx, ra.x, dy * ra.y);
+                            const float b2 = __builtin_fmaf(dx, rb.x, dy * rb.y);
+                            const float t2 = a2 - fabsf(b2);
+                            int decided = t2 > 0.f ? 1 : 0;
+                            const bool unsure = !(__builtin_fmaf(-fc.beta2, a2, fabsf(t2)) > fc.eps0) || ra.z <= -1e29f;
+                            if (__any(unsure)) {
+                                int exact = 0;
+                                if (p < tn) {
+                                    const float2 c = crd[p], d = dir_k[p];
+                                    exact = vote_exact(c.x, c.y, hp.x, hp.y, d.x, d.y, thresh) ? 1 : 0;
+                                }
+                                if (unsure) decided = exact;
                             }
-                            if (unsure) decided = exact;
+                            if (p >= tn) decided = 0;
+                            inl += decided - fast;
                         }
-                        if (p >= tn) decided = 0;
-                        inl += decided - fast;
                     }
+                    if (inl) atomicAdd(&sCnt[ht * 32 + col], inl);    // LDS: 2 lanes x 4 waves per hypothesis
                 }
-                if (inl) atomicAdd(&sCnt[ht * 32 + col], inl);    // LDS: 2 lanes x 4 waves per hypothesis
             }
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
-            const int h = ht0 * 32 + i;
-            const int c = sCnt[i];
-            if (h < hn && c != 0) atomicAdd(&counts[(size_t)bk * hn + h], c);
+            __syncthreads();
+            for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
+                const int h = ht0 * 32 + i;
+                const int c = sCnt[i];
+                if (h < hn && c != 0) atomicAdd(&counts[(size_t)bk * hn + h], c);
+            }
         }
     }
 }
