@@ -697,3 +697,42 @@ def test_whole_call_can_be_captured_in_a_hip_graph(oracle, synth, pkg, gpu):
     np.testing.assert_array_equal(_np(win), _np(win_e))
     want = oracle.ransac_voting_layer_v3(_np(d["mask"]), _np(d["vertex"]), 512, 0.99, idxs=_np(idxs))
     np.testing.assert_allclose(_np(out), want, rtol=0, atol=ATOL)
+
+
+def _soak_cases():
+    rng = np.random.RandomState(2026)
+    cases = []
+    for i in range(14):
+        cases.append(dict(H=int(rng.choice([48, 96, 130, 200])), W=int(rng.choice([64, 100, 160, 257])),
+                          K=int(rng.choice([1, 2, 5, 9, 17])), hn=int(rng.choice([32, 33, 64, 200, 512, 1000])),
+                          thresh=float(rng.choice([0.6, 0.9, 0.99, 0.995, 0.999, 0.9999])),
+                          fg=float(rng.choice([0.01, 0.05, 0.2, 0.6])), sigma=float(rng.choice([0.0, 0.02, 0.1, 0.5])),
+                          B=int(rng.choice([1, 2, 3])), seed=1000 + i))
+    return cases
+
+
+@pytest.mark.parametrize("case", _soak_cases(), ids=lambda c: "H%dW%dK%dhn%dT%g" % (c["H"], c["W"], c["K"], c["hn"], c["thresh"]))
+def test_randomized_soak_all_counts_bit_exact(oracle, synth, pkg, gpu, case):
+    """Random shapes / keypoint counts / hypothesis counts / thresholds / noise levels: every one of the B*K*hn inlier counts
+    and the hypotheses themselves must equal the oracle's, and the v3 means must be within 1e-4."""
+    from clean_pvnet_amd import ransac_voting as ext
+    c = dict(case)
+    thresh, hn, seed = c.pop("thresh"), c.pop("hn"), c.pop("seed")
+    d = synth.make_batch(**c, seed=seed)
+    mask, vertex = d["mask"], d["vertex"]
+    tn = [int(x) for x in (mask != 0).sum((1, 2))]
+    if min(tn) < 5:
+        pytest.skip("degenerate synthetic mask")
+    idxs = synth.make_idxs(tn, hn, c["K"], seed=seed)
+    mean = torch.zeros(c["B"], c["K"], 2)
+    det = []
+    oracle.estimate_voting_distribution_with_mean(_np(mask), _np(vertex), _np(mean), hn, hn, inlier_thresh=thresh,
+                                                  idxs=_np(idxs), details=det)
+    cov, hyp, counts, tnn = capi.estimate(mask.to(gpu), vertex.to(gpu), mean.to(gpu), hn, thresh, idxs=idxs.to(gpu))
+    for bi in range(c["B"]):
+        np.testing.assert_array_equal(_np(counts[bi]), det[bi]["counts"].T)
+        np.testing.assert_array_equal(_np(hyp[bi]), det[bi]["hypo_pts"].transpose(1, 0, 2))
+    out, win, t2, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), hn, thresh, 5, 30000, idxs.to(gpu), None, 0,
+                                             ext.SINGULAR_ZERO)
+    want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, thresh, idxs=_np(idxs), singular="zero")
+    np.testing.assert_allclose(_np(out), want, rtol=1e-6, atol=ATOL)
