@@ -332,6 +332,7 @@ int check_ptrs(const pvv_problem *p, const void *mask, const void *vertex, void 
 {
     if (int e = validate(p)) return e;
     if (!mask || !vertex || !ws) return fail(PVV_E_ARG, "mask, vertex and workspace must be non-NULL");
+    if ((uintptr_t)ws % 256 != 0) return fail(PVV_E_ARG, "workspace must be 256-byte aligned");
     *L = make_layout(p);
     if (ws_bytes < L->total) return fail(PVV_E_WORKSPACE, "workspace too small");
     return PVV_OK;
@@ -455,7 +456,8 @@ static int check_legacy(const void *a, const void *b, const void *c, const void 
 {
     if (!a || !b || !c || !d) return fail(PVV_E_ARG, "NULL device pointer");
     if (tn < 0 || vn <= 0 || hn < 0) return fail(PVV_E_ARG, "tn, hn must be >= 0 and vn > 0");
-    if ((long long)hn * vn * (long long)(tn > 0 ? tn : 1) >= (1ll << 40))
+    if ((long long)hn * vn >= (1ll << 29) || (long long)tn * vn >= (1ll << 29) ||
+        (long long)hn * vn * (long long)(tn > 0 ? tn : 1) >= (1ll << 40))
         return fail(PVV_E_ARG, "problem too large");
     return PVV_OK;
 }

@@ -120,7 +120,8 @@ typedef struct pvv_problem {
  * 8 sigma of the binomial subsample of P:135-138 (a longer list is truncated). */
 int32_t pvv_default_cap(int32_t H, int32_t W, int32_t max_num);
 
-/* Bytes of device scratch the two layer calls below need for `p`. */
+/* Bytes of device scratch the layer calls below need for `p`; the scratch must be
+ * 256-byte aligned (any hipMalloc / torch allocation is). */
 size_t pvv_workspace_bytes(const pvv_problem *p);
 
 /* ransac_voting_layer_v3 (P:112-199).

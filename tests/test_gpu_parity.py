@@ -736,3 +736,28 @@ def test_randomized_soak_all_counts_bit_exact(oracle, synth, pkg, gpu, case):
                                              ext.SINGULAR_ZERO)
     want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, thresh, idxs=_np(idxs), singular="zero")
     np.testing.assert_allclose(_np(out), want, rtol=1e-6, atol=ATOL)
+
+
+def test_batches_beyond_1024_images_are_split_by_the_python_layer(oracle, pkg, gpu):
+    """The count kernels keep their work-item table in LDS (<= 1024 images per launch, PVV_E_ARG beyond); the Python
+    layers split larger batches.  1030 tiny images, three of them checked against the oracle."""
+    from clean_pvnet_amd.ransac_voting_gpu import estimate_voting_distribution_with_mean, ransac_voting_layer_v3
+    B, H, W, K, hn = 1030, 16, 24, 2, 32
+    g = torch.Generator().manual_seed(9)
+    mask = (torch.rand(B, H, W, generator=g) < 0.4).to(torch.int64)
+    mask[5] = 0                                                           # an empty image in the first chunk
+    vertex = torch.randn(B, H, W, K, 2, generator=g)
+    tn = [int(x) for x in (mask != 0).sum((1, 2))]
+    idxs = torch.zeros(B, hn, K, 2, dtype=torch.int32)
+    for i, t in enumerate(tn):
+        if t > 0:
+            idxs[i] = torch.randint(0, t, (hn, K, 2), generator=g, dtype=torch.int32)
+    out = ransac_voting_layer_v3(mask.to(gpu), vertex.to(gpu), hn, inlier_thresh=0.9, idxs=idxs.to(gpu), singular="zero")
+    assert out.shape == (B, K, 2)
+    for bi in (0, 5, 1023, 1024, 1029):                                   # both sides of the chunk boundary
+        want = oracle.ransac_voting_layer_v3(_np(mask[bi:bi + 1]), _np(vertex[bi:bi + 1]), hn, 0.9, idxs=_np(idxs[bi:bi + 1]),
+                                             singular="zero")
+        np.testing.assert_allclose(_np(out[bi:bi + 1]), want, rtol=1e-5, atol=ATOL)
+    mean, cov = estimate_voting_distribution_with_mean(mask.to(gpu), vertex.to(gpu), out, 32, 32, inlier_thresh=0.9,
+                                                       idxs=idxs.to(gpu))
+    assert cov.shape == (B, K, 2, 2) and bool(torch.isfinite(cov).all())
