@@ -242,6 +242,18 @@ def cpu_leg(mask, vertex, tn, hn, K, thresh, n_sample, synth, gpu_out, budget_s=
     v = vertex[:n].cpu().numpy()
     idxs = synth.make_idxs([int(t) for t in tn[:n]], hn, K).numpy()
     vote_oracle.ransac_voting_layer_v3(m[:1], v[:1], hn, thresh, idxs=idxs[:1])       # warm-up
+    # host CPUs visible != CPUs usable (cgroup quotas): pick the OpenMP thread count that is actually fastest
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cand, best = sorted({max(1, avail >> s) for s in range(0, 6)} | {min(avail, 8)}, reverse=True), None
+    for nthr in cand:
+        vote_oracle.set_num_threads(nthr)
+        ts = time.perf_counter()
+        for _ in range(2):
+            vote_oracle.ransac_voting_layer_v3(m[:1], v[:1], hn, thresh, idxs=idxs[:1])
+        dt1 = (time.perf_counter() - ts) / 2
+        if best is None or dt1 < best[0]:
+            best = (dt1, nthr)
+    vote_oracle.set_num_threads(best[1])
     t0 = time.perf_counter()
     done = 0
     outs = {}

@@ -322,6 +322,15 @@ ORC_API void orc_estimate_image(const float *direct, const float *coords,
     }
 }
 
+ORC_API void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORC_API int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -312,3 +312,7 @@ def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
