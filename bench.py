@@ -180,6 +180,16 @@ def main():
                 estimate_voting_distribution_with_mean(mask, vertex, mean)
             torch.cuda.synchronize()
             extra["v3_plus_estimate_images_per_s"] = round(B * n2 / (time.perf_counter() - t2), 1)
+            # the reference's default (non-un_pnp) call, resnet18.py:75: 128 hypotheses on ~100 subsampled pixels
+            for _ in range(3):
+                ransac_voting_layer_v3(mask, vertex, 128, inlier_thresh=thresh, max_num=100)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            for _ in range(20):
+                kp = ransac_voting_layer_v3(mask, vertex, 128, inlier_thresh=thresh, max_num=100)
+            torch.cuda.synchronize()
+            extra["default_path_hn128_maxnum100_images_per_s"] = round(B * 20 / (time.perf_counter() - t4), 1)
+            extra["default_path_known_answer_max_err_px"] = round(float((kp - data["kpt_2d"]).abs().max()), 2)
             # decode_keypoint with torch.argmax + v3 vs the argmax fused into the mask scan
             from clean_pvnet_amd.decode import decode_keypoint
             x = torch.randn(B, 2 + 2 * K, H, W, device=dev) * 0.1
