@@ -761,3 +761,22 @@ def test_batches_beyond_1024_images_are_split_by_the_python_layer(oracle, pkg, g
     mean, cov = estimate_voting_distribution_with_mean(mask.to(gpu), vertex.to(gpu), out, 32, 32, inlier_thresh=0.9,
                                                        idxs=idxs.to(gpu))
     assert cov.shape == (B, K, 2, 2) and bool(torch.isfinite(cov).all())
+
+
+def test_full_hd_frame_with_subsampling(oracle, synth, pkg, gpu):
+    """1080x1920 (1013 compaction tiles, coordinates up to 1919), ~2 % foreground = 41 k pixels > max_num -> subsampled to
+    ~30 k with injected draws; K = 9, 512 hypotheses; counts bit-exact, means within 1e-4."""
+    from clean_pvnet_amd import ransac_voting as ext
+    c = dict(B=1, H=1080, W=1920, K=9, fg=0.02, sigma=0.05)
+    d = synth.make_batch(**c, seed=2025)
+    mask, vertex = d["mask"], d["vertex"]
+    selection = torch.rand(mask.shape, generator=torch.Generator().manual_seed(6))
+    fg = mask.sum((1, 2)).float()
+    assert float(fg[0]) > 30000
+    keep = (mask != 0) & (selection < (torch.tensor(30000.0) / fg).view(-1, 1, 1))
+    tn = [int(x) for x in keep.sum((1, 2))]
+    idxs = synth.make_idxs(tn, 512, 9, seed=2025)
+    out, win, tnn, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), 512, 0.99, 5, 30000, idxs.to(gpu),
+                                              selection.to(gpu), 0, ext.SINGULAR_REFERENCE)
+    assert _np(tnn).tolist() == tn
+    _check_v3(oracle, out, win, tnn, mask, vertex, idxs, 512, 0.99, selection=selection)
