@@ -91,12 +91,22 @@ def test_no_cpu_fallback(pkg):
                                   torch.zeros(3, 2, 4, dtype=torch.uint8), 0.99)
 
 
+def test_decode_and_weights_entry_points_have_no_cpu_path(pkg):
+    from clean_pvnet_amd import decode_keypoint, uncertainty_pnp_weights
+    out = {"seg": torch.zeros(1, 2, 8, 8), "vertex": torch.zeros(1, 4, 8, 8)}
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        decode_keypoint(out, un_pnp=False)
+    # the weights helper is plain tensor math (device-agnostic): diag(4, 9) -> inv(sqrtm) = diag(1/2, 1/3)
+    w = uncertainty_pnp_weights(torch.tensor([[[4.0, 0.0], [0.0, 9.0]]]))
+    torch.testing.assert_close(w, torch.tensor([[0.5, 0.0, 1.0 / 3.0]]))
+
+
 def test_missing_extension_fails_loudly(tmp_path):
     """Copy the Python side without the .so files: importing the layers must raise, not fall back."""
     import shutil
     dst = tmp_path / "clean-pvnet_amd"
     dst.mkdir()
-    for f in ("__init__.py", "ransac_voting_gpu.py"):
+    for f in ("__init__.py", "ransac_voting_gpu.py", "decode.py"):
         shutil.copy(os.path.join(ROOT, "clean-pvnet_amd", f), dst / f)
     code = ("import importlib.util,sys;"
             "spec=importlib.util.spec_from_file_location('clean_pvnet_amd', r'%s/__init__.py', submodule_search_locations=[r'%s']);"
