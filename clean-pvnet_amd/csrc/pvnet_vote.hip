@@ -70,6 +70,8 @@ struct Layout {
     size_t tile_nz, tile_sum, bits, tn, coords, dirs, recs, hyps, counts, sums, total;
 };
 
+bool needs_pixel_records(const pvv_problem *p);   // only k_count_fast reads the PixelRec array
+
 Layout make_layout(const pvv_problem *p)
 {
     Layout L;
@@ -83,7 +85,7 @@ Layout make_layout(const pvv_problem *p)
     L.tn = take(sizeof(int) * (size_t)p->B);
     L.coords = take(sizeof(float2) * (size_t)p->B * p->cap);
     L.dirs = take(sizeof(float2) * (size_t)p->B * p->K * p->cap);
-    L.recs = take(sizeof(PixelRec) * (size_t)p->B * p->K * p->cap);
+    L.recs = take(needs_pixel_records(p) ? sizeof(PixelRec) * (size_t)p->B * p->K * p->cap : 0);
     L.hyps = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
     L.counts = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
     L.sums = take(sizeof(double) * (size_t)p->B * p->K * kRefitSplit * 5);
@@ -161,6 +163,11 @@ bool use_bf16_count(const pvv_problem *p)
 {
     // block extents enter the guard band; keep pixel coordinates well inside f32/bf16-split integer range
     return count_kernel_choice() == 2 && use_fast_count(p->inlier_thresh) && p->H <= 16384 && p->W <= 16384;
+}
+
+bool needs_pixel_records(const pvv_problem *p)
+{
+    return use_fast_count(p->inlier_thresh) && !use_bf16_count(p);
 }
 
 Bf16Consts bf16_consts(float thresh)

@@ -38,7 +38,7 @@ def test_cabi_version_and_cap_and_validation():
     assert L.pvv_workspace_bytes(ctypes.byref(p)) == 0 and b"positive" in L.pvv_last_error()
     p.B, p.H, p.W, p.K, p.hn, p.mask_elem_size, p.cap = 2, 480, 640, 9, 512, 8, 31449
     n = L.pvv_workspace_bytes(ctypes.byref(p))
-    assert n > 2 * 9 * 31449 * (8 + 32)                       # dirs + records dominate
+    assert n > 2 * 9 * 31449 * 8                              # the planar dirs array dominates (no PixelRec for the default kernel)
     p.mask_elem_size = 3
     assert L.pvv_workspace_bytes(ctypes.byref(p)) == 0 and b"mask_elem_size" in L.pvv_last_error()
     p.mask_elem_size, p.B = 8, 5000
