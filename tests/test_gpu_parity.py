@@ -780,3 +780,39 @@ def test_full_hd_frame_with_subsampling(oracle, synth, pkg, gpu):
                                               selection.to(gpu), 0, ext.SINGULAR_REFERENCE)
     assert _np(tnn).tolist() == tn
     _check_v3(oracle, out, win, tnn, mask, vertex, idxs, 512, 0.99, selection=selection)
+
+
+def test_float_masks_and_strided_slices(oracle, synth, pkg, gpu):
+    """mask as float (converted like the reference: .byte() for v3, == 1 for estimate) and mask / vertex given as strided
+    slices of larger tensors (general-stride path of the mask scan and of the gather)."""
+    from clean_pvnet_amd.ransac_voting_gpu import estimate_voting_distribution_with_mean, ransac_voting_layer_v3
+    c = {**synth.CONFIGS["cfg1"], "B": 2}
+    d = synth.make_batch(**c, seed=71)
+    mask, vertex = d["mask"], d["vertex"]
+    H, W, K = c["H"], c["W"], c["K"]
+    tn = [int(x) for x in (mask != 0).sum((1, 2))]
+    idxs = synth.make_idxs(tn, 64, K, seed=71)
+    want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), 64, 0.99, idxs=_np(idxs))
+    # (a) float mask with a fractional value that .byte() truncates to 0 (torch semantics of :125)
+    fm = mask.float()
+    fm[0, 0, 0] = 0.7
+    got = ransac_voting_layer_v3(fm.to(gpu), vertex.to(gpu), 64, inlier_thresh=0.99, idxs=idxs.to(gpu))
+    np.testing.assert_allclose(_np(got), want, rtol=0, atol=ATOL)
+    # (b) every second row/column of a 2x larger int32 mask, vertex as a slice of a padded tensor
+    big_m = torch.zeros(2, 2 * H, 2 * W, dtype=torch.int32, device=gpu)
+    big_m[:, ::2, ::2] = mask.to(gpu).int()
+    mview = big_m[:, ::2, ::2]
+    big_v = torch.randn(2, H + 3, W + 5, K + 2, 2, device=gpu)
+    big_v[:, 1:H + 1, 2:W + 2, 1:K + 1] = vertex.to(gpu)
+    vview = big_v[:, 1:H + 1, 2:W + 2, 1:K + 1]
+    assert not mview.is_contiguous() and not vview.is_contiguous()
+    got = ransac_voting_layer_v3(mview, vview, 64, inlier_thresh=0.99, idxs=idxs.to(gpu))
+    np.testing.assert_allclose(_np(got), want, rtol=0, atol=ATOL)
+    # (c) estimate with a float mask: only entries == 1.0 are foreground
+    fm2 = mask.float() * 1.0
+    fm2[1][fm2[1] != 0] = 1.5
+    mean = d["kpt_2d"].clone()
+    ii = synth.make_idxs([tn[0], 0], 128, K, seed=72)
+    _m, wantc = oracle.estimate_voting_distribution_with_mean(_np(fm2), _np(vertex), _np(mean), 64, 128, idxs=_np(ii))
+    _m2, cov = estimate_voting_distribution_with_mean(fm2.to(gpu), vertex.to(gpu), mean.to(gpu), 64, 128, idxs=ii.to(gpu))
+    np.testing.assert_allclose(_np(cov), wantc, rtol=1e-4, atol=ATOL)
