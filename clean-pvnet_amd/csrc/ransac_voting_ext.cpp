@@ -12,6 +12,7 @@
 //     (-> Python RuntimeError) where the reference has CHECK_INPUT (ransac_voting.cpp:7-9) plus
 //     bare assert()s (kernel.cu:61-65) and exit() on a launch error (cuda_common.h:19-26).
 // This file contains no device code; it is compiled by the host compiler only.
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
 
@@ -88,6 +89,7 @@ Dims check_vote(const at::Tensor &direct, const at::Tensor &coords, const at::Te
 
 at::Tensor generate_hypothesis(at::Tensor direct, at::Tensor coords, at::Tensor idxs)
 {
+    const c10::DeviceGuard device_guard(direct.device());   // launch on the tensors' GPU, whatever the current device is
     Dims d = check_gen(direct, coords, idxs);
     auto hypo_pts = at::empty({d.hn, d.vn, 2}, direct.options());
     ok(pvv_generate_hypothesis(direct.data_ptr<float>(), coords.data_ptr<float>(), idxs.data_ptr<int32_t>(),
@@ -99,6 +101,7 @@ at::Tensor generate_hypothesis(at::Tensor direct, at::Tensor coords, at::Tensor 
 void voting_for_hypothesis(at::Tensor direct, at::Tensor coords, at::Tensor hypo_pts, at::Tensor inliers,
                            float inlier_thresh)
 {
+    const c10::DeviceGuard device_guard(direct.device());   // launch on the tensors' GPU, whatever the current device is
     Dims d = check_vote(direct, coords, hypo_pts, inliers, 2);
     ok(pvv_voting_for_hypothesis(direct.data_ptr<float>(), coords.data_ptr<float>(), hypo_pts.data_ptr<float>(),
                                  inliers.data_ptr<uint8_t>(), d.tn, d.vn, d.hn, inlier_thresh,
@@ -108,6 +111,7 @@ void voting_for_hypothesis(at::Tensor direct, at::Tensor coords, at::Tensor hypo
 
 at::Tensor generate_hypothesis_vanishing_point(at::Tensor direct, at::Tensor coords, at::Tensor idxs)
 {
+    const c10::DeviceGuard device_guard(direct.device());   // launch on the tensors' GPU, whatever the current device is
     Dims d = check_gen(direct, coords, idxs);
     auto hypo_pts = at::empty({d.hn, d.vn, 3}, direct.options());
     ok(pvv_generate_hypothesis_vanishing_point(direct.data_ptr<float>(), coords.data_ptr<float>(),
@@ -120,6 +124,7 @@ at::Tensor generate_hypothesis_vanishing_point(at::Tensor direct, at::Tensor coo
 void voting_for_hypothesis_vanishing_point(at::Tensor direct, at::Tensor coords, at::Tensor hypo_pts,
                                            at::Tensor inliers, float inlier_thresh)
 {
+    const c10::DeviceGuard device_guard(direct.device());   // launch on the tensors' GPU, whatever the current device is
     Dims d = check_vote(direct, coords, hypo_pts, inliers, 3);
     ok(pvv_voting_for_hypothesis_vanishing_point(direct.data_ptr<float>(), coords.data_ptr<float>(),
                                                  hypo_pts.data_ptr<float>(), inliers.data_ptr<uint8_t>(),
@@ -132,6 +137,7 @@ void voting_for_hypothesis_vanishing_point(at::Tensor direct, at::Tensor coords,
 // voting_for_hypothesis + sum over tn without the [hn,vn,tn] scratch -> [hn,vn] int32
 at::Tensor count_inliers(at::Tensor direct, at::Tensor coords, at::Tensor hypo_pts, float inlier_thresh)
 {
+    const c10::DeviceGuard device_guard(direct.device());   // launch on the tensors' GPU, whatever the current device is
     check_dev(direct, "direct", at::kFloat);
     check_dev(coords, "coords", at::kFloat);
     check_dev(hypo_pts, "hypo_pts", at::kFloat);
@@ -227,6 +233,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> ransac_voting_v3(
     int64_t max_num, std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection, int64_t seed,
     int64_t singular_policy)
 {
+    const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num,
                                  singular_policy, seed);
     const int32_t *ip = opt_idxs(idxs, vertex, p);
@@ -248,6 +255,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_v3(
     at::Tensor seg, at::Tensor vertex, int64_t round_hyp_num, double inlier_thresh, int64_t min_num, int64_t max_num,
     std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection, int64_t seed, int64_t singular_policy)
 {
+    const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     TORCH_CHECK(seg.is_cuda(), "seg must be a CUDA tensor");
     TORCH_CHECK(seg.scalar_type() == at::kFloat, "seg must be float32, got ", seg.scalar_type());
     TORCH_CHECK(seg.dim() == 4 && vertex.dim() == 5 && seg.size(0) == vertex.size(0) && seg.size(2) == vertex.size(1) &&
@@ -277,6 +285,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> estimate_
     int64_t min_num, int64_t max_num, std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection,
     int64_t seed, bool want_hyp)
 {
+    const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     pvv_problem p = make_problem(mask, vertex, hyp_total, inlier_thresh, min_num, max_num, 0, seed);
     check_dev(mean, "mean", at::kFloat);
     same_device(vertex, mean, "mean");
@@ -310,6 +319,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> estimate_
 void rerun_count_kernel(at::Tensor mask, at::Tensor vertex, int64_t hn, double inlier_thresh, int64_t min_num,
                         int64_t max_num, at::Tensor ws, bool zero_counts)
 {
+    const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     pvv_problem p = make_problem(mask, vertex, hn, inlier_thresh, min_num, max_num, 0, 0);
     check_dev(ws, "workspace", at::kByte);
     ok(pvv_rerun_count_kernel(&p, ws.data_ptr(), (size_t)ws.numel(), zero_counts ? 1 : 0, cur_stream(vertex)),
