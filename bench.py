@@ -216,6 +216,23 @@ def main():
                 torch.cuda.synchronize()
                 extra[name] = round(B * 20 / (time.perf_counter() - t3), 1)
             del decode_keypoint
+            # the ADD-S nearest-neighbour search at a LINEMOD-sized model (5841 points, both clouds)
+            import numpy as np
+            from clean_pvnet_amd.nn_utils import find_nearest_point_idx
+            from oracle import vote_oracle as _vo
+            rng = np.random.RandomState(0)
+            ref = (rng.randn(5841, 3) * 0.05).astype(np.float32)
+            que = (ref + rng.randn(5841, 3) * 0.002).astype(np.float32)
+            for _ in range(3):
+                idx = find_nearest_point_idx(ref, que)
+            t5 = time.perf_counter()
+            for _ in range(20):
+                idx = find_nearest_point_idx(ref, que)
+            extra["adds_nn_5841pts_ms_host_call"] = round(1e3 * (time.perf_counter() - t5) / 20, 3)
+            t6 = time.perf_counter()
+            want = _vo.find_nearest_point_idx(ref, que)
+            extra["adds_nn_5841pts_ms_cpu_oracle"] = round(1e3 * (time.perf_counter() - t6), 2)
+            extra["adds_nn_indices_equal_oracle"] = bool((idx == want).all())
 
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:

@@ -18,6 +18,7 @@ INCLUDE = os.path.join(ROOT, "include")
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpvnet_vote.so")
 EXT = os.path.join(HERE, "ransac_voting.so")
+NNLIB = os.path.join(HERE, "libpvnet_nn.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 # -ffp-contract=off is part of the numerical contract (bit-exact inlier counts), not a tuning flag.
@@ -55,6 +56,17 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+def build_nn(force=False, verbose=False):
+    """libpvnet_nn.so: the ADD-S nearest-neighbour search (include/pvnet_nn.h), hipcc, no torch."""
+    src = os.path.join(CSRC, "pvnet_nn.hip")
+    hdr = os.path.join(INCLUDE, "pvnet_nn.h")
+    if not force and _newer(NNLIB, src, hdr):
+        return NNLIB
+    hipcc = shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
+    _run([hipcc, *HIPCC_FLAGS, "-I" + INCLUDE, "-o", NNLIB, src], verbose)
+    return NNLIB
+
+
 def build_ext(force=False, verbose=False):
     src = os.path.join(CSRC, "ransac_voting_ext.cpp")
     hdr = os.path.join(INCLUDE, "pvnet_vote.h")
@@ -79,7 +91,7 @@ def build_ext(force=False, verbose=False):
 
 
 def build_all(force=False, verbose=False):
-    return build_lib(force, verbose), build_ext(force, verbose)
+    return build_lib(force, verbose), build_ext(force, verbose), build_nn(force, verbose)
 
 
 if __name__ == "__main__":

@@ -24,6 +24,7 @@
  *   lib/csrc/ransac_voting/src/ransac_voting_kernel.cu:268-310  voting_for_hypothesis_vanishing_point_kernel
  *   lib/csrc/ransac_voting/ransac_voting_gpu.py:150-196         select + refit of ransac_voting_layer_v3
  *   lib/csrc/ransac_voting/ransac_voting_gpu.py:231-269         rounds + covariance of estimate_voting_distribution_with_mean
+ *   lib/csrc/nn/src/nearest_neighborhood.cu:48-117              findNearestPoint{2D,3D}IdxKernel
  */
 #include <math.h>
 #include <stdint.h>
@@ -320,6 +321,28 @@ ORC_API void orc_estimate_image(const float *direct, const float *coords,
         cov[vi * 4 + 2] = (float)(sxy / den);
         cov[vi * 4 + 3] = (float)(syy / den);
     }
+}
+
+/* lib/csrc/nn/src/nearest_neighborhood.cu:48-117 -- index of the nearest reference point per query, binary32
+ * squared distance in the reference's operand order, `dist < min_dist` (first minimum wins). */
+ORC_API void orc_find_nearest(const float *ref_pts, const float *que_pts, int32_t *idxs, int b, int pn1, int pn2,
+                              int dim, int exclude_self)
+{
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int bi = 0; bi < b; ++bi)
+        for (int p2i = 0; p2i < pn2; ++p2i) {
+            const float *q = que_pts + ((size_t)bi * pn2 + p2i) * dim;
+            float min_dist = 3.402823466e+38F; /* FLT_MAX, :67 */
+            int min_idx = 0;
+            for (int p1i = 0; p1i < pn1; ++p1i) {
+                if (exclude_self && p1i == p2i) continue;
+                const float *r = ref_pts + ((size_t)bi * pn1 + p1i) * dim;
+                float dist = (r[0] - q[0]) * (r[0] - q[0]) + (r[1] - q[1]) * (r[1] - q[1]);
+                if (dim == 3) dist = dist + (r[2] - q[2]) * (r[2] - q[2]);
+                if (dist < min_dist) { min_dist = dist; min_idx = p1i; }
+            }
+            idxs[(size_t)bi * pn2 + p2i] = min_idx;
+        }
 }
 
 ORC_API void orc_set_num_threads(int n)

@@ -310,6 +310,17 @@ def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256
     return mean, cov
 
 
+def find_nearest_point_idx(ref_pts, que_pts, exclude_self=False):
+    """nearest_neighborhood.cu:48-117 through nn_utils.find_nearest_point_idx's interface: ref [pn1,dim], que [pn2,dim]
+    -> int32 [pn2]."""
+    ref, que = _c(ref_pts, np.float32), _c(que_pts, np.float32)
+    assert ref.shape[1] == que.shape[1] and 1 < que.shape[1] <= 3
+    idxs = np.zeros(que.shape[0], np.int32)
+    lib().orc_find_nearest(_p(ref, _f32p), _p(que, _f32p), _p(idxs, _i32p), 1, ref.shape[0], que.shape[0], ref.shape[1],
+                           int(bool(exclude_self)))
+    return idxs
+
+
 def num_threads():
     return int(lib().orc_num_threads())
 
