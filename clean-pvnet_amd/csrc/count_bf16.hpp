@@ -147,12 +147,14 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
         __syncthreads();
         const float C1 = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
         const float eps = fc.eps0 + fc.eps_c * C1;
+        const float epsw = __builtin_fmaf(fc.beta * 1.02f, C1, eps);   // band half-width at |h'| = 0
 
         const int p0 = pb + wave * kBfPixPerWave;               // this wave's 128 pixels
         const int npix = min(tn - p0, kBfPixPerWave);           // may be <= 0
 
         // ---- A operands: lane l = row l%32 (form = row/16, pixel = row%16), k = 8*(l/32)..+7 of
-        //      (v0,v0,v0,v1,v1,v2 of vx | vy0,vy0 || vy0,vy1,vy1,vy2 | cv0,cv1,cv2, 0); built once per item
+        //      (vx0,vy0,vx0,vx0,vx1,vy0,vy0,vy1 || vx2,vy2,vx1,vy1, cv0,cv1,cv2, 0); built once per item.  The order of
+        //      the 15 terms is free; this one puts (qx0,qy0) first in BOTH k halves of the B operand (band width below)
         bf16x8 A[8];
         const int form = (lane >> 4) & 1, prow = lane & 15;
         auto make_A = [&](int j) -> bf16x8 {
@@ -162,8 +164,8 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
             split3(v.y, vy);
             split3(v.z, cv);
             const __bf16 zero = (__bf16)0.f;
-            const bf16x8 lo8 = {vx[0], vx[0], vx[0], vx[1], vx[1], vx[2], vy[0], vy[0]};
-            const bf16x8 hi8 = {vy[0], vy[1], vy[1], vy[2], cv[0], cv[1], cv[2], zero};
+            const bf16x8 lo8 = {vx[0], vy[0], vx[0], vx[0], vx[1], vy[0], vy[0], vy[1]};
+            const bf16x8 hi8 = {vx[2], vy[2], vx[1], vy[1], cv[0], cv[1], cv[2], zero};
             return kslice ? hi8 : lo8;
         };
         if (npix > 0) {
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
             const int ht0 = g * htpi;
             const int nht = min(nt, ht0 + htpi) - ht0;
             // ---- B operands of this group: lane l of tile ht holds column l%32, k = 8*(l/32)..+7 of
-            //      (qx0,qx1,qx2,qx0,qx1,qx0, qy0,qy1 | qy2,qy0,qy1,qy0, 1,1,1,0),  q = pieces of h' = fl(h - o)
+            //      (qx0,qy0,qx1,qx2,qx0,qy1,qy2,qy0 || qx0,qy0,qx1,qy1, 1,1,1,0),  q = pieces of h' = fl(h - o)
             int far = 0;
             for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
                 const int h = (ht0 + (i >> 5)) * 32 + (i & 31);
@@ -189,8 +191,8 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
                 split3(hp.x - org.x, qx);
                 split3(hp.y - org.y, qy);
                 const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
-                const bf16x8 lo8 = {qx[0], qx[1], qx[2], qx[0], qx[1], qx[0], qy[0], qy[1]};
-                const bf16x8 hi8 = {qy[2], qy[0], qy[1], qy[0], one, one, one, zero};
+                const bf16x8 lo8 = {qx[0], qy[0], qx[1], qx[2], qx[0], qy[1], qy[2], qy[0]};
+                const bf16x8 hi8 = {qx[0], qy[0], qx[1], qy[1], one, one, one, zero};
                 sB[(i >> 5) * 64 + (i & 31)] = lo8;
                 sB[(i >> 5) * 64 + 32 + (i & 31)] = hi8;
                 sCnt[i] = 0;        // zeroed and (below) flushed by the same thread
@@ -215,6 +217,13 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
                     const bf16x8 Bop = sB[ht * 64 + lane];
                     int inl = 0;
                     unsigned flagged = 0u;                            // wave-uniform: tiles with an evaluation in the band
+                    // conservative band half-width of this lane's hypothesis for the whole item: a = d.nh <= |d|_2 <=
+                    // |h'|_1 + |c'|_1 <= (|qx0| + |qy0|) (1 + 2^-8) + C1 -- the leading bf16 pieces are the first two elements
+                    // of either half of the B operand; the 2 % slack covers that and the roundings of a
+                    const unsigned q01 = __builtin_bit_cast(uint4, Bop).x;
+                    const float wband = __builtin_fmaf(fc.beta * 1.02f,
+                                                       fabsf(__uint_as_float(q01 << 16)) + fabsf(__uint_as_float(q01 & 0xffff0000u)),
+                                                       epsw);
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         unsigned q = 0u;
@@ -222,17 +231,16 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
                         for (int jj = 0; jj < 4; ++jj) {
                             const int j = half * 4 + jj;
                             const float16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j], Bop, zero16, 0, 0, 0);
-                            // conservative band test per tile: min |t|  vs  beta * max a + eps  (|t| - beta a <= eps for some
-                            // evaluation implies it); the per-evaluation measure is only formed in the rare path below
-                            float tmin = INFINITY, amax = 0.f;
+                            // conservative band test per tile: min |t|  vs  beta * (bound on a) + eps  (|t| - beta a <= eps for
+                            // some evaluation implies it); the per-evaluation measure is only formed in the rare path below
+                            float tmin = INFINITY;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 const float t = acc[e] - fabsf(acc[8 + e]);
                                 q = __builtin_amdgcn_alignbit(q, __float_as_uint(t), 31);
                                 tmin = fminf(tmin, fabsf(t));
-                                amax = fmaxf(amax, acc[e]);
                             }
-                            flagged |= __ballot(tmin <= __builtin_fmaf(fc.beta, amax, eps)) ? (1u << j) : 0u;
+                            flagged |= __ballot(tmin <= wband) ? (1u << j) : 0u;
                         }
                         inl += 32 - __popc(q);                        // 4 tiles x 8 evaluations, sign bit set = not an inlier
                     }

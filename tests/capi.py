@@ -7,7 +7,8 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "pvnet_vote.h")
-LIBPATH = os.path.join(ROOT, "clean-pvnet_amd", "libpvnet_vote.so")
+# PVV_LIBPATH: tools/variant_time.py points the same binding at an experimental build of the library
+LIBPATH = os.environ.get("PVV_LIBPATH") or os.path.join(ROOT, "clean-pvnet_amd", "libpvnet_vote.so")
 
 c_i32, c_i64, c_u64, c_f32, vp, sz = (ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float,
                                        ctypes.c_void_p, ctypes.c_size_t)
