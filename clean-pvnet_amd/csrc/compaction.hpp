@@ -17,6 +17,7 @@ struct MaskArgs {
     int W, HW, T;
     int min_num, max_num, cap;
     uint64_t seed;
+    int b0;                  // first_image: RNG key offset of image 0
     // fused argmax (decode_keypoint): when seg != nullptr the mask value is argmax_c seg[b,c,y,x]
     const float *seg;
     long long *mask_out;     // [B,H,W] int64 or nullptr
@@ -75,7 +76,7 @@ __device__ __forceinline__ int mask_weight(const MaskArgs &a, int b, int p)
 __device__ __forceinline__ float selection_draw(const MaskArgs &a, int b, int p)
 {
     if (a.selection) return a.selection[(int64_t)b * a.HW + p];
-    return (float)(rng_u32(a.seed, 0u, (uint32_t)b, (uint32_t)p) >> 8) * 0x1p-24f;
+    return (float)(rng_u32(a.seed, 0u, (uint32_t)(a.b0 + b), (uint32_t)p) >> 8) * 0x1p-24f;
 }
 
 // Pass 1 -- the ONLY pass that reads the mask: per tile of 2048 pixels the foreground count, the weight sum

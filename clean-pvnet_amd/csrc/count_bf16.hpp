@@ -149,28 +149,45 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
         const float eps = fc.eps0 + fc.eps_c * C1;
         const float epsw = __builtin_fmaf(fc.beta * 1.02f, C1, eps);   // band half-width at |h'| = 0
 
-        const int p0 = pb + wave * kBfPixPerWave;               // this wave's 128 pixels
-        const int npix = min(tn - p0, kBfPixPerWave);           // may be <= 0
+        // 16-pixel tiles of the chunk go round-robin to the 4 waves (tile 4*j + wave is this wave's j-th): a partial
+        // chunk keeps all four waves busy and nobody multiplies tiles that hold no pixel
+        const int ntile_c = (min(tn - pb, PC) + 15) >> 4;       // tiles of the chunk with at least one pixel (1..32)
+        const int ntile_w = (ntile_c - wave + 3) >> 2;          // this wave's share (0..8)
 
         // ---- A operands: lane l = row l%32 (form = row/16, pixel = row%16), k = 8*(l/32)..+7 of
         //      (vx0,vy0,vx0,vx0,vx1,vy0,vy0,vy1 || vx2,vy2,vx1,vy1, cv0,cv1,cv2, 0); built once per item.  The order of
-        //      the 15 terms is free; this one puts (qx0,qy0) first in BOTH k halves of the B operand (band width below)
+        //      the 15 terms is free; this one puts (qx0,qy0) first in BOTH k halves of the B operand (band width below).
+        //      Lanes l and l+32 need the two k halves of the SAME row, so they share the work: the lower lane splits the
+        //      row for tiles 0-3, the upper one for tiles 4-7, each forms both halves, and one v_permlane32_swap per
+        //      register hands the partner its half.
         bf16x8 A[8];
-        const int form = (lane >> 4) & 1, prow = lane & 15;
-        auto make_A = [&](int j) -> bf16x8 {
-            const float4 v = sP[(wave * kBfPixPerWave + j * 16 + prow) * 2 + form];
-            __bf16 vx[3], vy[3], cv[3];
-            split3(v.x, vx);
-            split3(v.y, vy);
-            split3(v.z, cv);
-            const __bf16 zero = (__bf16)0.f;
-            const bf16x8 lo8 = {vx[0], vy[0], vx[0], vx[0], vx[1], vy[0], vy[0], vy[1]};
-            const bf16x8 hi8 = {vx[2], vy[2], vx[1], vy[1], cv[0], cv[1], cv[2], zero};
-            return kslice ? hi8 : lo8;
-        };
-        if (npix > 0) {
+        if (ntile_w > 0) {
+            const int form = (lane >> 4) & 1, prow = lane & 15;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) A[j] = make_A(j);
+            for (int i = 0; i < 4; ++i) {
+                const int j = kslice * 4 + i;
+                const float4 v = sP[((j * 4 + wave) * 16 + prow) * 2 + form];
+                __bf16 vx[3], vy[3], cv[3];
+                split3(v.x, vx);
+                split3(v.y, vy);
+                split3(v.z, cv);
+                const __bf16 zero = (__bf16)0.f;
+                const bf16x8 lo8 = {vx[0], vy[0], vx[0], vx[0], vx[1], vy[0], vy[0], vy[1]};
+                const bf16x8 hi8 = {vx[2], vy[2], vx[1], vy[1], cv[0], cv[1], cv[2], zero};
+                uint4 x = __builtin_bit_cast(uint4, lo8), y = __builtin_bit_cast(uint4, hi8);
+                // swap(x, y): lanes 32-63 of x <-> lanes 0-31 of y.  Afterwards x = this lane's k half of tile i (own lo8
+                // below 32, the partner's hi8 above), y = this lane's k half of tile 4 + i
+                {
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(x.x, y.x, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(x.y, y.y, false, false);
+                    const auto r2 = __builtin_amdgcn_permlane32_swap(x.z, y.z, false, false);
+                    const auto r3 = __builtin_amdgcn_permlane32_swap(x.w, y.w, false, false);
+                    x = make_uint4(r0[0], r1[0], r2[0], r3[0]);
+                    y = make_uint4(r0[1], r1[1], r2[1], r3[1]);
+                }
+                A[i] = __builtin_bit_cast(bf16x8, x);
+                A[4 + i] = __builtin_bit_cast(bf16x8, y);
+            }
         }
         const int ebase = kslice * 4;                            // this lane's pixels: ebase + e%4 + 8*(e/4)
         const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -206,16 +223,15 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
                     if (h >= hn) continue;
                     const float2 hp = hyp_k[h];
                     int inl = 0;
-                    for (int p = p0 + kslice; p < p0 + npix; p += 2) {
+                    for (int p = pb + wave * 2 + kslice; p < min(tn, pb + PC); p += 8) {
                         const float2 c = crd[p], d = dir_k[p];
                         inl += vote_exact(c.x, c.y, hp.x, hp.y, d.x, d.y, thresh) ? 1 : 0;
                     }
                     if (inl) atomicAdd(&sCnt[ht * 32 + col], inl);
                 }
-            } else if (npix > 0) {
+            } else if (ntile_w > 0) {
                 for (int ht = 0; ht < nht; ++ht) {
                     const bf16x8 Bop = sB[ht * 64 + lane];
-                    int inl = 0;
                     unsigned flagged = 0u;                            // wave-uniform: tiles with an evaluation in the band
                     // conservative band half-width of this lane's hypothesis for the whole item: a = d.nh <= |d|_2 <=
                     // |h'|_1 + |c'|_1 <= (|qx0| + |qy0|) (1 + 2^-8) + C1 -- the leading bf16 pieces are the first two elements
@@ -224,62 +240,76 @@ __global__ __launch_bounds__(kBlock) void k_count_bf16(
                     const float wband = __builtin_fmaf(fc.beta * 1.02f,
                                                        fabsf(__uint_as_float(q01 << 16)) + fabsf(__uint_as_float(q01 & 0xffff0000u)),
                                                        epsw);
+                    unsigned qs[2] = {0u, 0u};                        // sign-bit queues, one per 4 tiles (newest evaluation = bit 0)
+                    unsigned mb[2] = {0u, 0u};                        // in-band evaluations of flagged tiles: bit 8*(j%4) + e
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        unsigned q = 0u;
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const int j = half * 4 + jj;
+                    for (int j = 0; j < 8; ++j) {
+                        if (j < ntile_w) {
                             const float16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j], Bop, zero16, 0, 0, 0);
-                            // conservative band test per tile: min |t|  vs  beta * (bound on a) + eps  (|t| - beta a <= eps for
-                            // some evaluation implies it); the per-evaluation measure is only formed in the rare path below
+                            // conservative band test per tile: min |t|  vs  beta * (bound on a) + eps
                             float tmin = INFINITY;
+                            float t[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                const float t = acc[e] - fabsf(acc[8 + e]);
-                                q = __builtin_amdgcn_alignbit(q, __float_as_uint(t), 31);
-                                tmin = fminf(tmin, fabsf(t));
+                                t[e] = acc[e] - fabsf(acc[8 + e]);
+                                qs[j >> 2] = __builtin_amdgcn_alignbit(qs[j >> 2], __float_as_uint(t[e]), 31);
+                                tmin = fminf(tmin, fabsf(t[e]));
                             }
-                            flagged |= __ballot(tmin <= wband) ? (1u << j) : 0u;
+                            if (__builtin_expect(__ballot(tmin <= wband) != 0, 0)) {
+                                // rare (a few % of the tiles): mark the evaluations that really are inside the band,
+                                // |t| - beta a <= eps, while a and t are still in registers; they are re-decided below
+                                unsigned m = 0u;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e)
+                                    m |= (__builtin_fmaf(-fc.beta, acc[e], fabsf(t[e])) <= eps) ? (1u << e) : 0u;
+                                mb[j >> 2] |= m << (8 * (j & 3));
+                                flagged |= 1u << j;
+                            }
                         }
-                        inl += 32 - __popc(q);                        // 4 tiles x 8 evaluations, sign bit set = not an inlier
                     }
-                    while (__builtin_expect(flagged != 0u, 0)) {
-                        // rare: tile j holds an evaluation inside the guard band.  Re-derive its operands, repeat the
-                        // MFMA (bitwise the same result) and re-decide the flagged evaluations exactly (K:100-125).
-                        const int j = __builtin_ctz(flagged);
-                        flagged &= flagged - 1;
-                        const float16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(make_A(j), Bop, zero16, 0, 0, 0);
+                    int inl = 8 * ntile_w - __popc(qs[0]) - __popc(qs[1]);   // sign bit set = not an inlier
+                    if (__builtin_expect(flagged != 0u, 0)) {
+                        // (loading the un-translated hypothesis here, not ahead of the tiles: the prefetch costs more issue
+                        // slots in every iteration than the stall does in every third, measured +1.6 %)
                         const int h = (ht0 + ht) * 32 + col;
                         const float2 hp = h < hn ? hyp_k[h] : make_float2(0.f, 0.f);
+                        do {
+                            // re-decide the marked evaluations of tile j exactly (K:100-125)
+                            const int j = __builtin_ctz(flagged);
+                            flagged &= flagged - 1;
+                            const unsigned m = mb[j >> 2] >> (8 * (j & 3));
+                            if (!__any((m & 0xffu) != 0u)) continue;
+                            // position of evaluation (j, e) in its sign queue: tiles pushed after it, 8 bits each, then 7 - e
+                            const int after = min(ntile_w - (j & 4), 4) - 1 - (j & 3);
+                            const unsigned sgn = qs[j >> 2] >> (8 * after);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float t = acc[e] - fabsf(acc[8 + e]);
-                            const float z = __builtin_fmaf(-fc.beta, acc[e], fabsf(t));
-                            if (!__any(z <= eps)) continue;
-                            const int prow = j * 16 + ebase + (e & 3) + 8 * (e >> 2);
-                            const int p = p0 + prow;
-                            const int fast = (__float_as_uint(t) >> 31) ? 0 : 1;
-                            // second level: the sqrt/divide-free test of k_count_fast on d = fl(h - c) (the exact path's own
-                            // d) with the f32 unit normal from LDS; its band (beta2, eps0) is ~10x narrower than the MFMA's
-                            const float4 ra = sP[(wave * kBfPixPerWave + prow) * 2], rb = sP[(wave * kBfPixPerWave + prow) * 2 + 1];
-                            const float dx = hp.x - (ra.w + org.x), dy = hp.y - (rb.w + org.y);
-                            const float a2 = __builtin_fmaf(dx, ra.x, dy * ra.y);
-                            const float b2 = __builtin_fmaf(dx, rb.x, dy * rb.y);
-                            const float t2 = a2 - fabsf(b2);
-                            int decided = t2 > 0.f ? 1 : 0;
-                            const bool unsure = !(__builtin_fmaf(-fc.beta2, a2, fabsf(t2)) > fc.eps0) || ra.z <= -1e29f;
-                            if (__any(unsure)) {
-                                int exact = 0;
-                                if (p < tn) {
-                                    const float2 c = crd[p], d = dir_k[p];
-                                    exact = vote_exact(c.x, c.y, hp.x, hp.y, d.x, d.y, thresh) ? 1 : 0;
+                            for (int e = 0; e < 8; ++e) {
+                                const bool marked = (m >> e) & 1u;
+                                if (!__any(marked)) continue;
+                                const int prow = (j * 4 + wave) * 16 + ebase + (e & 3) + 8 * (e >> 2);
+                                const int p = pb + prow;
+                                const int fast = ((sgn >> (7 - e)) & 1u) ? 0 : 1;
+                                // second level: the sqrt/divide-free test of k_count_fast on d = fl(h - c) (the exact path's own
+                                // d) with the f32 unit normal from LDS; its band (beta2, eps0) is ~10x narrower than the MFMA's
+                                const float4 ra = sP[prow * 2], rb = sP[prow * 2 + 1];
+                                const float dx = hp.x - (ra.w + org.x), dy = hp.y - (rb.w + org.y);
+                                const float a2 = __builtin_fmaf(dx, ra.x, dy * ra.y);
+                                const float b2 = __builtin_fmaf(dx, rb.x, dy * rb.y);
+                                const float t2 = a2 - fabsf(b2);
+                                int decided = t2 > 0.f ? 1 : 0;
+                                const bool unsure = marked && (!(__builtin_fmaf(-fc.beta2, a2, fabsf(t2)) > fc.eps0) || ra.z <= -1e29f);
+                                if (__any(unsure)) {
+                                    int exact = 0;
+                                    if (unsure && p < tn) {
+                                        const float2 c = crd[p], d = dir_k[p];
+                                        exact = vote_exact(c.x, c.y, hp.x, hp.y, d.x, d.y, thresh) ? 1 : 0;
+                                    }
+                                    if (unsure) decided = exact;
                                 }
-                                if (unsure) decided = exact;
+                                if (p >= tn) decided = 0;
+                                if (marked) inl += decided - fast;
                             }
-                            if (p >= tn) decided = 0;
-                            inl += decided - fast;
-                        }
+                        } while (flagged != 0u);
                     }
                     if (inl) atomicAdd(&sCnt[ht * 32 + col], inl);    // LDS: 2 lanes x 4 waves per hypothesis
                 }

@@ -10,7 +10,7 @@
 __global__ __launch_bounds__(kBlock) void k_gen_hypothesis(
     const int32_t *__restrict__ idxs /*[B,hn,K,2] or null*/, const int *__restrict__ tn_arr,
     const float2 *__restrict__ coords, const float2 *__restrict__ dirs, float2 *__restrict__ hyps,
-    int *__restrict__ counts, int B, int K, int hn, int cap, uint64_t seed)
+    int *__restrict__ counts, int B, int K, int hn, int cap, uint64_t seed, int b0)
 {
     const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= (long long)B * K * hn) return;
@@ -33,8 +33,8 @@ __global__ __launch_bounds__(kBlock) void k_gen_hypothesis(
         t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
     } else {
         uint32_t c = (uint32_t)(hi * K + vi) * 2u;
-        t0 = (int)(rng_u32(seed, 1u, (uint32_t)b, c) % (uint32_t)tn);
-        t1 = (int)(rng_u32(seed, 1u, (uint32_t)b, c + 1u) % (uint32_t)tn);
+        t0 = (int)(rng_u32(seed, 1u, (uint32_t)(b0 + b), c) % (uint32_t)tn);
+        t1 = (int)(rng_u32(seed, 1u, (uint32_t)(b0 + b), c + 1u) % (uint32_t)tn);
     }
     const float2 *dp = dirs + ((size_t)b * K + vi) * cap;
     const float2 *cp = coords + (size_t)b * cap;

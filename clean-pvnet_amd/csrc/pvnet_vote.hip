@@ -308,6 +308,7 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
     m.W = p->W; m.HW = p->H * p->W; m.T = L.T;
     m.min_num = p->min_num; m.max_num = p->max_num; m.cap = p->cap;
     m.seed = p->seed;
+    m.b0 = p->first_image;
     VertexArgs v;
     v.vertex = d_vertex;
     v.sb = p->vertex_stride[0]; v.sh = p->vertex_stride[1]; v.sw = p->vertex_stride[2];
@@ -329,7 +330,7 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
     hipLaunchKernelGGL(k_gen_hypothesis, dim3((unsigned)((nh + kBlock - 1) / kBlock)), dim3(kBlock),
                        0, st, d_idxs, (const int *)(ws + L.tn), (const float2 *)(ws + L.coords),
                        (const float2 *)(ws + L.dirs), (float2 *)(ws + L.hyps), (int *)(ws + L.counts),
-                       p->B, p->K, p->hn, p->cap, p->seed);
+                       p->B, p->K, p->hn, p->cap, p->seed, p->first_image);
     if ((e = check_launch("k_gen_hypothesis"))) return e;
     return launch_count_any(p, L, ws, st);
 }

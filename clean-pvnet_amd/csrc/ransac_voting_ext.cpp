@@ -231,11 +231,12 @@ at::Tensor make_workspace(const pvv_problem &p, const at::Tensor &like)
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> ransac_voting_v3(
     at::Tensor mask, at::Tensor vertex, int64_t round_hyp_num, double inlier_thresh, int64_t min_num,
     int64_t max_num, std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection, int64_t seed,
-    int64_t singular_policy)
+    int64_t singular_policy, int64_t first_image)
 {
     const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num,
                                  singular_policy, seed);
+    p.first_image = (int32_t)first_image;
     const int32_t *ip = opt_idxs(idxs, vertex, p);
     const float *sp = opt_selection(selection, vertex, p);
     at::Tensor ws = make_workspace(p, vertex);
@@ -253,7 +254,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> ransac_voting_v3(
 // -> (kpt [b,vn,2], mask [b,h,w] int64, win_counts [b,vn], tn [b])
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_v3(
     at::Tensor seg, at::Tensor vertex, int64_t round_hyp_num, double inlier_thresh, int64_t min_num, int64_t max_num,
-    std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection, int64_t seed, int64_t singular_policy)
+    std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection, int64_t seed, int64_t singular_policy,
+    int64_t first_image)
 {
     const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     TORCH_CHECK(seg.is_cuda(), "seg must be a CUDA tensor");
@@ -263,6 +265,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_v3(
                 "seg must be [b,c,h,w] matching vertex [b,h,w,vn,2]");
     auto mask = at::empty({seg.size(0), seg.size(2), seg.size(3)}, seg.options().dtype(at::kLong));
     pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, singular_policy, seed);
+    p.first_image = (int32_t)first_image;
     p.seg_classes = (int32_t)seg.size(1);
     for (int i = 0; i < 4; ++i) p.seg_stride[i] = seg.stride(i);
     const int32_t *ip = opt_idxs(idxs, vertex, p);
@@ -283,10 +286,11 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_v3(
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> estimate_voting_distribution(
     at::Tensor mask, at::Tensor vertex, at::Tensor mean, int64_t hyp_total, double inlier_thresh,
     int64_t min_num, int64_t max_num, std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection,
-    int64_t seed, bool want_hyp)
+    int64_t seed, bool want_hyp, int64_t first_image)
 {
     const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     pvv_problem p = make_problem(mask, vertex, hyp_total, inlier_thresh, min_num, max_num, 0, seed);
+    p.first_image = (int32_t)first_image;
     check_dev(mean, "mean", at::kFloat);
     same_device(vertex, mean, "mean");
     TORCH_CHECK(mean.dim() == 3 && mean.size(0) == p.B && mean.size(1) == p.K && mean.size(2) == 2,
@@ -339,10 +343,20 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           "voting for hypothesis vanishing point");
     // fused / batched additions
     m.def("count_inliers", &count_inliers, "fused vote + count -> [hn,vn] int32");
-    m.def("ransac_voting_v3", &ransac_voting_v3, "batched ransac_voting_layer_v3");
-    m.def("decode_keypoint_v3", &decode_keypoint_v3, "argmax(seg) fused with batched ransac_voting_layer_v3");
+    // first_image: index of image 0 in the caller's larger batch (device RNG key), so that a batch split over several
+    // calls draws the same numbers as one call
+    namespace py = pybind11;
+    m.def("ransac_voting_v3", &ransac_voting_v3, "batched ransac_voting_layer_v3", py::arg("mask"), py::arg("vertex"),
+          py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"), py::arg("idxs"),
+          py::arg("selection"), py::arg("seed"), py::arg("singular_policy"), py::arg("first_image") = 0);
+    m.def("decode_keypoint_v3", &decode_keypoint_v3, "argmax(seg) fused with batched ransac_voting_layer_v3",
+          py::arg("seg"), py::arg("vertex"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"),
+          py::arg("max_num"), py::arg("idxs"), py::arg("selection"), py::arg("seed"), py::arg("singular_policy"),
+          py::arg("first_image") = 0);
     m.def("estimate_voting_distribution", &estimate_voting_distribution,
-          "batched estimate_voting_distribution_with_mean");
+          "batched estimate_voting_distribution_with_mean", py::arg("mask"), py::arg("vertex"), py::arg("mean"),
+          py::arg("hyp_total"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"), py::arg("idxs"),
+          py::arg("selection"), py::arg("seed"), py::arg("want_hyp"), py::arg("first_image") = 0);
     m.def("rerun_count_kernel", &rerun_count_kernel, "re-launch the inlier-count kernel (profiling aid)");
     m.attr("abi_version") = pvv_abi_version();
     m.attr("SINGULAR_REFERENCE") = (int)PVV_SINGULAR_REFERENCE;

@@ -53,11 +53,12 @@ def _vote_v3(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, idxs,
     b = vertex.shape[0]
     mask = _as_mask(mask, False)
     outs = []
-    for lo, hi in _chunks(b):
+    seed = _next_seed()     # one key for the whole batch; the device RNG is keyed by (seed, image index), so the
+    for lo, hi in _chunks(b):   # split below is invisible in the results
         out, _win, _tn, _ws = _ext.ransac_voting_v3(
             mask[lo:hi], vertex[lo:hi], int(round_hyp_num), float(inlier_thresh), int(min_num), int(max_num),
             None if idxs is None else idxs[lo:hi], None if selection is None else selection[lo:hi],
-            _next_seed(), policy)
+            seed, policy, lo)
         outs.append(out)
     return outs[0] if len(outs) == 1 else torch.cat(outs)
 
@@ -142,11 +143,12 @@ def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256
     mask = _as_mask(mask, True)
     mean_c = mean.contiguous().float()
     covs, hyps, ratios, wts = [], [], [], []
+    seed = _next_seed()
     for lo, hi in _chunks(b):
         cov, hyp, counts, tn, w = _ext.estimate_voting_distribution(
             mask[lo:hi], vertex[lo:hi], mean_c[lo:hi], hn_total, float(inlier_thresh), int(min_num),
             int(max_num), None if idxs is None else idxs[lo:hi],
-            None if selection is None else selection[lo:hi], _next_seed(), bool(output_hyp))
+            None if selection is None else selection[lo:hi], seed, bool(output_hyp), lo)
         covs.append(cov)
         wts.append(w)
         if output_hyp:

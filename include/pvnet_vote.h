@@ -30,7 +30,7 @@ extern "C" {
 #define PVV_E_WORKSPACE (-2) /* workspace smaller than pvv_workspace_bytes() */
 
 /* ABI version of this header; pvv_abi_version() must return the same. */
-#define PVV_ABI_VERSION 2
+#define PVV_ABI_VERSION 3
 
 int pvv_abi_version(void);
 const char *pvv_last_error(void);
@@ -101,7 +101,9 @@ typedef struct pvv_problem {
                                 d_selection are NULL                           */
     /* pvv_decode_keypoint_v3 only (ignored elsewhere): the segmentation logits */
     int32_t seg_classes;     /* C of seg [B,C,H,W] (2 for PVNet, config.py:108-112) */
-    int32_t reserved_;
+    int32_t first_image;     /* index of image 0 of this call in the caller's larger batch: the device RNG is keyed
+                                by (seed, first_image + b), so a batch split over several calls draws the same
+                                numbers as one call.  0 for a whole batch (was reserved_, keep 0 if unsure) */
     int64_t seg_stride[4];   /* element strides of seg [B,C,H,W] (a channel slice
                                 of the network output, resnet18.py:93)          */
 } pvv_problem;

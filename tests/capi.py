@@ -19,7 +19,7 @@ class Problem(ctypes.Structure):
                 ("mask_elem_size", c_i32), ("min_num", c_i32), ("max_num", c_i32), ("cap", c_i32),
                 ("singular_policy", c_i32), ("inlier_thresh", c_f32),
                 ("mask_stride", c_i64 * 3), ("vertex_stride", c_i64 * 5), ("seed", c_u64),
-                ("seg_classes", c_i32), ("reserved_", c_i32), ("seg_stride", c_i64 * 4)]
+                ("seg_classes", c_i32), ("first_image", c_i32), ("seg_stride", c_i64 * 4)]
 
 
 def declared_symbols():

@@ -763,6 +763,23 @@ def test_batches_beyond_1024_images_are_split_by_the_python_layer(oracle, pkg, g
     assert cov.shape == (B, K, 2, 2) and bool(torch.isfinite(cov).all())
 
 
+def test_device_rng_is_keyed_by_global_image_index(synth, pkg, gpu):
+    """pvv_problem.first_image: a batch cut into several calls with the same seed draws the same hypothesis pairs AND
+    the same subsampling numbers as one call (device RNG, nothing injected) -- the split the Python layer makes beyond
+    1024 images is invisible in the results."""
+    from clean_pvnet_amd import ransac_voting as ext
+    d = synth.make_batch(B=6, H=96, W=128, K=3, fg=0.15, sigma=0.05, seed=77, device=gpu)
+    mask, vertex = d["mask"], d["vertex"]
+    for max_num in (30000, 400):                                          # 400 < tn: the selection draws matter too
+        whole = ext.ransac_voting_v3(mask, vertex, 64, 0.99, 5, max_num, None, None, 4242, ext.SINGULAR_ZERO)
+        parts = [ext.ransac_voting_v3(mask[lo:hi], vertex[lo:hi], 64, 0.99, 5, max_num, None, None, 4242,
+                                      ext.SINGULAR_ZERO, lo) for lo, hi in ((0, 1), (1, 4), (4, 6))]
+        for i in range(3):                                                # keypoints, winning counts, tn
+            assert torch.equal(whole[i], torch.cat([q[i] for q in parts]))
+        other = ext.ransac_voting_v3(mask[1:4], vertex[1:4], 64, 0.99, 5, max_num, None, None, 4242, ext.SINGULAR_ZERO)
+        assert not torch.equal(other[1], parts[1][1])                     # first_image = 0 there: different draws
+
+
 def test_full_hd_frame_with_subsampling(oracle, synth, pkg, gpu):
     """1080x1920 (1013 compaction tiles, coordinates up to 1919), ~2 % foreground = 41 k pixels > max_num -> subsampled to
     ~30 k with injected draws; K = 9, 512 hypotheses; counts bit-exact, means within 1e-4."""

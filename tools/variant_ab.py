@@ -1,0 +1,106 @@
+"""Interleaved A/B timing of the inlier-count kernel of several builds of libpvnet_vote.so in ONE process (same
+device buffers, alternating groups of launches), because run-to-run and box-to-box spread (+-2 %) hides the small
+steps.  Prints mean, standard error and the ratio to the first library per build.
+
+    gpurun -- 'python tools/variant_ab.py build/variants/a.so build/variants/b.so --rounds 40'
+"""
+import argparse
+import ctypes
+import importlib.util
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import capi  # noqa: E402
+
+
+def _synth():
+    spec = importlib.util.spec_from_file_location("pvv_synth", os.path.join(ROOT, "clean-pvnet_amd", "synth.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _load(path):
+    L = ctypes.CDLL(os.path.abspath(path))
+    L.pvv_last_error.restype = ctypes.c_char_p
+    L.pvv_workspace_bytes.restype = ctypes.c_size_t
+    L.pvv_workspace_bytes.argtypes = [ctypes.POINTER(capi.Problem)]
+    L.pvv_default_cap.restype = ctypes.c_int32
+    L.pvv_default_cap.argtypes = [ctypes.c_int32] * 3
+    vp = ctypes.c_void_p
+    L.pvv_ransac_voting_v3.argtypes = [ctypes.POINTER(capi.Problem), vp, vp, vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp]
+    L.pvv_rerun_count_kernel.argtypes = [ctypes.POINTER(capi.Problem), vp, ctypes.c_size_t, ctypes.c_int, vp]
+    return L
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="+")
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--hn", type=int, default=0)
+    ap.add_argument("--rounds", type=int, default=30)
+    ap.add_argument("--per-group", type=int, default=10)
+    a = ap.parse_args()
+    synth = _synth()
+    cfg = dict(synth.CONFIGS[a.config])
+    B = a.batch or cfg["B"]
+    hn = a.hn or cfg["hn"]
+    dev = torch.device("cuda:0")
+    d = synth.make_batch(B, cfg["H"], cfg["W"], cfg["K"], device=dev,
+                         **{k: v for k, v in cfg.items() if k not in ("B", "H", "W", "K", "hn")})
+    mask, vertex = d["mask"], d["vertex"]
+    st = capi.stream()
+    runs = []
+    for path in a.libs:
+        L = _load(path)
+        p = capi.Problem()
+        p.B, p.H, p.W, p.K, _ = vertex.shape
+        p.hn = hn
+        p.mask_elem_size = mask.element_size()
+        p.min_num, p.max_num = 5, cfg.get("max_num", 30000)
+        p.cap = L.pvv_default_cap(p.H, p.W, p.max_num)
+        p.inlier_thresh = cfg.get("thresh", 0.99)
+        p.mask_stride[:] = mask.stride()
+        p.vertex_stride[:] = vertex.stride()
+        p.seed = 12345
+        n = L.pvv_workspace_bytes(ctypes.byref(p))
+        ws = torch.empty(n, dtype=torch.uint8, device=dev)
+        out = torch.empty(p.B, p.K, 2, device=dev)
+        win = torch.empty(p.B, p.K, dtype=torch.int32, device=dev)
+        tn = torch.empty(p.B, dtype=torch.int32, device=dev)
+        rc = L.pvv_ransac_voting_v3(ctypes.byref(p), capi.ptr(mask), capi.ptr(vertex), None, None, capi.ptr(ws), n,
+                                    capi.ptr(out), capi.ptr(win), capi.ptr(tn), st)
+        assert rc == 0, L.pvv_last_error()
+        torch.cuda.synchronize()
+        runs.append(dict(path=path, L=L, p=p, ws=ws, n=n, win=int(win.sum().item()), out=out.double().sum().item(), ms=[]))
+    for r in runs:
+        for _ in range(5):
+            r["L"].pvv_rerun_count_kernel(ctypes.byref(r["p"]), capi.ptr(r["ws"]), r["n"], 0, st)
+    torch.cuda.synchronize()
+    for _ in range(a.rounds):
+        for r in runs:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.per_group):
+                r["L"].pvv_rerun_count_kernel(ctypes.byref(r["p"]), capi.ptr(r["ws"]), r["n"], 0, st)
+            e1.record()
+            torch.cuda.synchronize()
+            r["ms"].append(e0.elapsed_time(e1) / a.per_group)
+    base = None
+    for r in runs:
+        t = torch.tensor(r["ms"], dtype=torch.float64)
+        mean, sem = t.mean().item(), (t.std().item() / len(t) ** 0.5)
+        base = base or mean
+        print(json.dumps({"lib": os.path.basename(r["path"]), "config": a.config, "B": B, "hn": hn,
+                          "ms_mean": round(mean, 4), "ms_sem": round(sem, 5), "ms_min": round(t.min().item(), 4),
+                          "ratio": round(mean / base, 4), "win_sum": r["win"], "out_sum": round(r["out"], 3)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
