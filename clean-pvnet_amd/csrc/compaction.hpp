@@ -18,6 +18,7 @@ struct MaskArgs {
     int min_num, max_num, cap;
     uint64_t seed;
     int b0;                  // first_image: RNG key offset of image 0
+    int *tn_user;            // the caller's tn[B] (or nullptr): written beside the workspace copy, no D2D copy later
     // fused argmax (decode_keypoint): when seg != nullptr the mask value is argmax_c seg[b,c,y,x]
     const float *seg;
     long long *mask_out;     // [B,H,W] int64 or nullptr
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
                                                     PixelRec *__restrict__ recs)
 {
     __shared__ long long redl[4];
-    __shared__ int red[4];
+    __shared__ int red[8];
     __shared__ int seg[kTileSteps * 4 + 1];
     __shared__ unsigned short list[kTile];
     const int t = blockIdx.x, b = blockIdx.y;
@@ -205,29 +206,45 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
 
     if (t != 0 && tile_nz[b * a.T + t] == 0) return;  // background-only tile: nothing to scatter
 
-    const long long fg = image_fg(tile_sum, b, a.T, redl);
-    if (fg < (long long)a.min_num) {  // P:129-132 / P:211-216: image skipped
-        if (t == 0 && threadIdx.x == 0) tn_out[b] = 0;
-        return;
-    }
-
-    int before = 0, total = 0;
-    for (int i = threadIdx.x; i < a.T; i += kBlock) {
-        int c = tile_nz[b * a.T + i];
-        total += c;
-        if (i < t) before += c;
-    }
-    before = block_sum(before, red);
-    total = block_sum(total, red);
-    if (t == 0 && threadIdx.x == 0) tn_out[b] = total < a.cap ? total : a.cap;
-
+    // this tile's foreground map, requested before the reductions below so that the two latencies overlap
     const unsigned long long *wb = bits + ((size_t)b * a.T + t) * (kTileSteps * 4);
     unsigned long long word[kTileSteps];
 #pragma unroll
-    for (int s = 0; s < kTileSteps; ++s) {
-        word[s] = wb[s * 4 + wave];                       // wave-uniform
-        if (lane == 0) seg[s * 4 + wave] = __popcll(word[s]);
+    for (int s = 0; s < kTileSteps; ++s) word[s] = wb[s * 4 + wave];   // wave-uniform
+
+    // one pass over the image's tile table and ONE block reduction for all three sums: foreground_num (P:126 / P:208),
+    // the rows before this tile, and the image's row count
+    long long fgs = 0;
+    int before = 0, total = 0;
+    for (int i = threadIdx.x; i < a.T; i += kBlock) {
+        fgs += tile_sum[b * a.T + i];
+        const int c = tile_nz[b * a.T + i];
+        total += c;
+        if (i < t) before += c;
     }
+    fgs = wave_sum(fgs);
+    before = wave_sum(before);
+    total = wave_sum(total);
+    if (lane == 0) { redl[wave] = fgs; red[wave] = before; red[4 + wave] = total; }
+    __syncthreads();
+    const long long fg = redl[0] + redl[1] + redl[2] + redl[3];
+    before = red[0] + red[1] + red[2] + red[3];
+    total = red[4] + red[5] + red[6] + red[7];
+    if (fg < (long long)a.min_num) {  // P:129-132 / P:211-216: image skipped
+        if (t == 0 && threadIdx.x == 0) {
+            tn_out[b] = 0;
+            if (a.tn_user) a.tn_user[b] = 0;
+        }
+        return;
+    }
+    if (t == 0 && threadIdx.x == 0) {
+        tn_out[b] = total < a.cap ? total : a.cap;
+        if (a.tn_user) a.tn_user[b] = tn_out[b];
+    }
+
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s)
+        if (lane == 0) seg[s * 4 + wave] = __popcll(word[s]);
     __syncthreads();
     if (threadIdx.x < 64) {  // wave 0: exclusive scan of the 32 (step,wave) segment counts
         int c = threadIdx.x < kTileSteps * 4 ? seg[threadIdx.x] : 0;
@@ -243,7 +260,6 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
 
     // foreground pixels of the tile -> LDS list (in rank order), so that the K-fold gather below is spread over
     // all 256 threads instead of looping inside the few lanes that own a foreground pixel
-    __syncthreads();
 #pragma unroll
     for (int s = 0; s < kTileSteps; ++s) {
         const unsigned long long m = word[s];

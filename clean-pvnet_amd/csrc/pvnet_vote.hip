@@ -88,7 +88,7 @@ Layout make_layout(const pvv_problem *p)
     L.recs = take(needs_pixel_records(p) ? sizeof(PixelRec) * (size_t)p->B * p->K * p->cap : 0);
     L.hyps = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
     L.counts = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
-    L.sums = take(sizeof(double) * (size_t)p->B * p->K * kRefitSplit * 5);
+    L.sums = take(sizeof(double) * (size_t)p->B * p->K * kRefitSplitMax * 5);
     L.total = off;
     return L;
 }
@@ -292,7 +292,7 @@ int launch_compaction(const MaskArgs &m, const VertexArgs &v, const Layout &L, c
 // compaction + hypotheses + counting, shared by both layers
 int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d_vertex,
               const int32_t *d_idxs, const float *d_selection, char *ws, const Layout &L,
-              hipStream_t st, const float *d_seg = nullptr, int64_t *d_mask_out = nullptr)
+              hipStream_t st, int32_t *d_tn, const float *d_seg = nullptr, int64_t *d_mask_out = nullptr)
 {
     MaskArgs m;
     m.mask = d_mask;
@@ -309,6 +309,7 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
     m.min_num = p->min_num; m.max_num = p->max_num; m.cap = p->cap;
     m.seed = p->seed;
     m.b0 = p->first_image;
+    m.tn_user = d_tn;
     VertexArgs v;
     v.vertex = d_vertex;
     v.sb = p->vertex_stride[0]; v.sh = p->vertex_stride[1]; v.sw = p->vertex_stride[2];
@@ -369,21 +370,21 @@ PVV_EXPORT size_t pvv_workspace_bytes(const pvv_problem *p)
 }
 
 static int finish_v3(const pvv_problem *p, const Layout &L, char *ws, float *d_out, int32_t *d_win_counts,
-                     int32_t *d_tn, hipStream_t st)
+                     hipStream_t st)
 {
-    hipLaunchKernelGGL(k_select_refit, dim3(p->K * kRefitSplit, p->B), dim3(kBlock), 0, st,
+    // blocks per (keypoint, image): the largest power of two that keeps the grid within ~6 blocks per CU (measured on
+    // MI355X: 2 at B*K = 576, 8 for a single image)
+    int nsplit = kRefitSplitMax;
+    while (nsplit > 1 && (long long)p->B * p->K * nsplit > 6ll * num_cus()) nsplit >>= 1;
+    hipLaunchKernelGGL(k_select_refit, dim3(p->K * nsplit, p->B), dim3(kBlock), 0, st,
                        (const int *)(ws + L.tn), (const float2 *)(ws + L.coords),
                        (const float2 *)(ws + L.dirs), (const float2 *)(ws + L.hyps),
                        (const int *)(ws + L.counts), (double *)(ws + L.sums), d_win_counts, p->K, p->hn,
-                       p->cap, p->inlier_thresh);
+                       p->cap, p->inlier_thresh, nsplit);
     if (int e = check_launch("k_select_refit")) return e;
     hipLaunchKernelGGL(k_finalize_v3, dim3(p->B), dim3(64), 0, st, (const int *)(ws + L.tn),
-                       (const double *)(ws + L.sums), (float2 *)d_out, p->K, p->singular_policy);
+                       (const double *)(ws + L.sums), (float2 *)d_out, p->K, p->singular_policy, nsplit);
     if (int e = check_launch("k_finalize_v3")) return e;
-    if (d_tn) {
-        hipError_t e = hipMemcpyAsync(d_tn, ws + L.tn, sizeof(int) * p->B, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-    }
     return PVV_OK;
 }
 
@@ -397,8 +398,8 @@ PVV_EXPORT int pvv_ransac_voting_v3(const pvv_problem *p, const void *d_mask, co
     if (!d_out) return fail(PVV_E_ARG, "d_out is NULL");
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)d_workspace;
-    if (int e = run_front(p, 0, d_mask, d_vertex, d_idxs, d_selection, ws, L, st)) return e;
-    return finish_v3(p, L, ws, d_out, d_win_counts, d_tn, st);
+    if (int e = run_front(p, 0, d_mask, d_vertex, d_idxs, d_selection, ws, L, st, d_tn)) return e;
+    return finish_v3(p, L, ws, d_out, d_win_counts, st);
 }
 
 PVV_EXPORT int pvv_decode_keypoint_v3(const pvv_problem *p, const float *d_seg, const float *d_vertex,
@@ -413,8 +414,8 @@ PVV_EXPORT int pvv_decode_keypoint_v3(const pvv_problem *p, const float *d_seg, 
     if (p->seg_classes < 1 || p->seg_classes > 256) return fail(PVV_E_ARG, "seg_classes must be in [1, 256]");
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)d_workspace;
-    if (int e = run_front(p, 0, nullptr, d_vertex, d_idxs, d_selection, ws, L, st, d_seg, d_mask_out)) return e;
-    return finish_v3(p, L, ws, d_out, d_win_counts, d_tn, st);
+    if (int e = run_front(p, 0, nullptr, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, d_seg, d_mask_out)) return e;
+    return finish_v3(p, L, ws, d_out, d_win_counts, st);
 }
 
 PVV_EXPORT int pvv_estimate_voting_distribution(const pvv_problem *p, const void *d_mask,
@@ -429,16 +430,12 @@ PVV_EXPORT int pvv_estimate_voting_distribution(const pvv_problem *p, const void
     if (!d_mean || !d_cov) return fail(PVV_E_ARG, "d_mean / d_cov is NULL");
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)d_workspace;
-    if (int e = run_front(p, 1, d_mask, d_vertex, d_idxs, d_selection, ws, L, st)) return e;
+    if (int e = run_front(p, 1, d_mask, d_vertex, d_idxs, d_selection, ws, L, st, d_tn)) return e;
     hipLaunchKernelGGL(k_covariance, dim3(p->K, p->B), dim3(kBlock), 0, st,
                        (const int *)(ws + L.tn), (const float2 *)(ws + L.hyps),
                        (const int *)(ws + L.counts), (const float2 *)d_mean, d_cov, (float2 *)d_hyp,
                        d_counts, d_weights, p->K, p->hn);
     if (int e = check_launch("k_covariance")) return e;
-    if (d_tn) {
-        hipError_t e = hipMemcpyAsync(d_tn, ws + L.tn, sizeof(int) * p->B, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-    }
     return PVV_OK;
 }
 

@@ -7,23 +7,26 @@
 // Stage 4 (v3): winner selection + least-squares refit (P:159-167 and P:176-196).
 // One block per (keypoint, image).
 // ---------------------------------------------------------------------------------------------
-// kRefitSplit blocks per (keypoint, image), each over a quarter of the pixels: the exact re-vote is a long
-// dependent chain (two sqrt, one divide) and 576 blocks alone leave the SIMDs latency-bound.  Partial sums go to
-// sums[b,vi,split,5] and are merged in a fixed order by k_finalize_v3 (deterministic).
-constexpr int kRefitSplit = 4;
+// nsplit (1..kRefitSplitMax) blocks per (keypoint, image), each over its share of the pixels: the exact re-vote is a
+// long dependent chain (two sqrt, one divide) and B*K blocks alone leave the SIMDs latency-bound, while more than
+// about one wave of blocks only adds dispatch time; the host picks nsplit from B*K (refit_split).  Partial sums go to
+// sums[b,vi,split,5] and are merged in a fixed order by k_finalize_v3 (deterministic for a given launch shape).
+// (Finalising in the last block of an image to arrive was tried: the device-scope release/acquire it needs writes
+// back and invalidates the XCD's L2 on gfx950 and cost 30 % of the whole call.)
+constexpr int kRefitSplitMax = 8;
 
 __global__ __launch_bounds__(kBlock) void k_select_refit(
     const int *__restrict__ tn_arr, const float2 *__restrict__ coords,
     const float2 *__restrict__ dirs, const float2 *__restrict__ hyps,
-    const int *__restrict__ counts, double *__restrict__ sums /*[B,K,kRefitSplit,5]*/,
-    int *__restrict__ win_counts /*[B,K] or null*/, int K, int hn, int cap, float thresh)
+    const int *__restrict__ counts, double *__restrict__ sums /*[B,K,nsplit,5]*/,
+    int *__restrict__ win_counts /*[B,K] or null*/, int K, int hn, int cap, float thresh, int nsplit)
 {
     __shared__ int s_cnt[4], s_idx[4];
     __shared__ double red5[20];
-    const int vi = blockIdx.x / kRefitSplit, split = blockIdx.x % kRefitSplit, b = blockIdx.y;
+    const int vi = blockIdx.x / nsplit, split = blockIdx.x - vi * nsplit, b = blockIdx.y;
     const int bk = b * K + vi;
     const int tn = tn_arr[b];
-    double *part = sums + ((size_t)bk * kRefitSplit + split) * 5;
+    double *part = sums + ((size_t)bk * nsplit + split) * 5;
     if (tn <= 0) {
         if (threadIdx.x == 0) {
             for (int i = 0; i < 5; ++i) part[i] = 0.0;
@@ -58,8 +61,8 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
     const float2 *dp = dirs + (size_t)bk * cap;
     const float2 *cq = coords + (size_t)b * cap;
     double xx = 0, xy = 0, yy = 0, bx = 0, by = 0;
-    // this block's quarter of the pixels; four pixels per trip so that the loads of a trip overlap
-    const int per = (tn + kRefitSplit - 1) / kRefitSplit;
+    // this block's share of the pixels; four pixels per trip so that the loads of a trip overlap
+    const int per = (tn + nsplit - 1) / nsplit;
     const int tbeg = split * per, tend = min(tn, tbeg + per);
     for (int t0 = tbeg + threadIdx.x; t0 < tend; t0 += 4 * kBlock) {
         float2 d[4], c[4];
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
 // Merge the partial normal equations, solve the 2x2 systems (P:193, closed form in binary64) and apply the
 // singular-matrix policy across the keypoints of an image (b_inv, P:97-109).  One block per image.
 __global__ __launch_bounds__(64) void k_finalize_v3(const int *__restrict__ tn_arr, const double *__restrict__ sums,
-                                                    float2 *__restrict__ out, int K, int policy)
+                                                    float2 *__restrict__ out, int K, int policy, int nsplit)
 {
     __shared__ int any_singular;
     const int b = blockIdx.x;
@@ -110,9 +113,9 @@ __global__ __launch_bounds__(64) void k_finalize_v3(const int *__restrict__ tn_a
         double bx = 0, by = 0;
         bool sing = false;
         if (vi < K && !skipped) {
-            const double *q = sums + ((size_t)b * K + vi) * kRefitSplit * 5;
+            const double *q = sums + ((size_t)b * K + vi) * nsplit * 5;
             double xx = 0, xy = 0, yy = 0;
-            for (int sp = 0; sp < kRefitSplit; ++sp) {
+            for (int sp = 0; sp < nsplit; ++sp) {
                 xx += q[sp * 5]; xy += q[sp * 5 + 1]; yy += q[sp * 5 + 2]; bx += q[sp * 5 + 3]; by += q[sp * 5 + 4];
             }
             const double det = xx * yy - xy * xy;
@@ -142,9 +145,9 @@ __global__ __launch_bounds__(64) void k_finalize_v3(const int *__restrict__ tn_a
     for (int vi = threadIdx.x; vi < K; vi += 64) {
         float2 o = make_float2(0.f, 0.f);
         if (!skipped) {
-            const double *q = sums + ((size_t)b * K + vi) * kRefitSplit * 5;
+            const double *q = sums + ((size_t)b * K + vi) * nsplit * 5;
             double xx = 0, xy = 0, yy = 0, bx = 0, by = 0;
-            for (int sp = 0; sp < kRefitSplit; ++sp) {
+            for (int sp = 0; sp < nsplit; ++sp) {
                 xx += q[sp * 5]; xy += q[sp * 5 + 1]; yy += q[sp * 5 + 2]; bx += q[sp * 5 + 3]; by += q[sp * 5 + 4];
             }
             const double det = xx * yy - xy * xy;

@@ -17,12 +17,12 @@ while [ $# -gt 0 ]; do
     *) echo "unknown arg $1"; exit 1;;
   esac
 done
-if [ ${#sedargs[@]} -gt 0 ]; then sed -i -E "${sedargs[@]}" "$scratch"/count_bf16.hpp; fi
+if [ ${#sedargs[@]} -gt 0 ]; then sed -i -E "${sedargs[@]}" "$scratch"/*.hpp "$scratch"/*.hip; fi
 mkdir -p "$ROOT/build/variants"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -fPIC -shared \
   -fvisibility=hidden "${defs[@]}" -I"$ROOT/include" -I"$scratch" -o "$ROOT/build/variants/$name.so" "$scratch/pvnet_vote.hip"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -S --cuda-device-only \
   "${defs[@]}" -I"$ROOT/include" -I"$scratch" -o "$ROOT/build/variants/$name.s" "$scratch/pvnet_vote.hip" 2>/dev/null
 grep -E "k_count_bf16.*\.(num_vgpr|private_seg_size)," "$ROOT/build/variants/$name.s" | sed 's/.*Consts\w*\././'
-diff -u "$ROOT/clean-pvnet_amd/csrc/count_bf16.hpp" "$scratch/count_bf16.hpp" | grep '^[+-]' | grep -v '^+++\|^---' || true
+diff -ru "$ROOT/clean-pvnet_amd/csrc" "$scratch" --exclude="*.cpp" | grep '^[+-]' | grep -v '^+++\|^---' || true
 rm -rf "$scratch"

@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--hn", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=30)
     ap.add_argument("--per-group", type=int, default=10)
+    ap.add_argument("--mode", default="count", choices=["count", "v3"],
+                    help="count: re-launches of the inlier-count kernel; v3: whole pvv_ransac_voting_v3 calls")
     a = ap.parse_args()
     synth = _synth()
     cfg = dict(synth.CONFIGS[a.config])
@@ -78,17 +80,26 @@ def main():
                                     capi.ptr(out), capi.ptr(win), capi.ptr(tn), st)
         assert rc == 0, L.pvv_last_error()
         torch.cuda.synchronize()
-        runs.append(dict(path=path, L=L, p=p, ws=ws, n=n, win=int(win.sum().item()), out=out.double().sum().item(), ms=[]))
+        args = (ctypes.byref(p), capi.ptr(mask), capi.ptr(vertex), None, None, capi.ptr(ws), n, capi.ptr(out), capi.ptr(win),
+                capi.ptr(tn), st)
+        runs.append(dict(path=path, L=L, p=p, ws=ws, n=n, win=int(win.sum().item()), out=out.double().sum().item(), ms=[],
+                         args=args, keep=(out, win, tn)))
+    def launch(r):
+        if a.mode == "v3":
+            r["L"].pvv_ransac_voting_v3(*r["args"])
+        else:
+            r["L"].pvv_rerun_count_kernel(ctypes.byref(r["p"]), capi.ptr(r["ws"]), r["n"], 0, st)
+
     for r in runs:
         for _ in range(5):
-            r["L"].pvv_rerun_count_kernel(ctypes.byref(r["p"]), capi.ptr(r["ws"]), r["n"], 0, st)
+            launch(r)
     torch.cuda.synchronize()
     for _ in range(a.rounds):
         for r in runs:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.per_group):
-                r["L"].pvv_rerun_count_kernel(ctypes.byref(r["p"]), capi.ptr(r["ws"]), r["n"], 0, st)
+                launch(r)
             e1.record()
             torch.cuda.synchronize()
             r["ms"].append(e0.elapsed_time(e1) / a.per_group)
@@ -97,7 +108,7 @@ def main():
         t = torch.tensor(r["ms"], dtype=torch.float64)
         mean, sem = t.mean().item(), (t.std().item() / len(t) ** 0.5)
         base = base or mean
-        print(json.dumps({"lib": os.path.basename(r["path"]), "config": a.config, "B": B, "hn": hn,
+        print(json.dumps({"lib": os.path.basename(r["path"]), "mode": a.mode, "config": a.config, "B": B, "hn": hn,
                           "ms_mean": round(mean, 4), "ms_sem": round(sem, 5), "ms_min": round(t.min().item(), 4),
                           "ratio": round(mean / base, 4), "win_sum": r["win"], "out_sum": round(r["out"], 3)}), flush=True)
 
