@@ -276,21 +276,42 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
         const int y = p / a.W;
         coords[(size_t)b * a.cap + before + i] = make_float2((float)(p - y * a.W), (float)y);
     }
-    for (int i = threadIdx.x; i < n * v.K; i += kBlock) {
-        const int vi = i / n, li = i - vi * n;                           // consecutive threads -> consecutive rows
-        const int p = t * kTile + list[li];
-        const int y = p / a.W;
-        const int x = p - y * a.W;
-        const float *src = v.vertex + (int64_t)b * v.sb + (int64_t)y * v.sh + (int64_t)x * v.sw + (int64_t)vi * v.sk;
-        float2 d;
-        if (v.vec2) {
-            d = *(const float2 *)src;
-        } else {
-            d.x = src[0];
-            d.y = src[v.sc];
+    // n*K gathers of 8 bytes each; four per thread in flight (all loads of a trip before its stores), otherwise every
+    // trip of the loop pays a full memory latency: 9 trips at K = 9 and ~250 foreground pixels per tile
+    constexpr int kGather = 4;
+    const int total_g = n * v.K;
+    for (int i0 = threadIdx.x; i0 < total_g; i0 += kGather * kBlock) {
+        float2 d[kGather];
+        size_t row[kGather];
+        int xs[kGather], ys[kGather];
+#pragma unroll
+        for (int u = 0; u < kGather; ++u) {
+            const int i = i0 + u * kBlock;
+            d[u] = make_float2(0.f, 0.f);
+            row[u] = 0;
+            xs[u] = ys[u] = 0;
+            if (i < total_g) {
+                const int vi = i / n, li = i - vi * n;                   // consecutive threads -> consecutive rows
+                const int p = t * kTile + list[li];
+                const int y = p / a.W;
+                const int x = p - y * a.W;
+                const float *src = v.vertex + (int64_t)b * v.sb + (int64_t)y * v.sh + (int64_t)x * v.sw + (int64_t)vi * v.sk;
+                if (v.vec2) {
+                    d[u] = *(const float2 *)src;
+                } else {
+                    d[u].x = src[0];
+                    d[u].y = src[v.sc];
+                }
+                row[u] = ((size_t)b * v.K + vi) * a.cap + before + li;
+                xs[u] = x; ys[u] = y;
+            }
         }
-        const size_t row = ((size_t)b * v.K + vi) * a.cap + before + li;
-        dirs[row] = d;
-        if (v.kappa != 0.0) recs[row] = make_record((float)x, (float)y, d.x, d.y, v.kappa);
+#pragma unroll
+        for (int u = 0; u < kGather; ++u) {
+            if (i0 + u * kBlock < total_g) {
+                dirs[row[u]] = d[u];
+                if (v.kappa != 0.0) recs[row[u]] = make_record((float)xs[u], (float)ys[u], d[u].x, d[u].y, v.kappa);
+            }
+        }
     }
 }

@@ -5,6 +5,8 @@ covariances within 1e-4 (absolute for means -- pixel units; absolute + relative 
 Every layer is exercised both through the pybind11 module (what clean-pvnet imports) and through the
 raw C ABI of include/pvnet_vote.h (tests/capi.py).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -700,9 +702,11 @@ def test_whole_call_can_be_captured_in_a_hip_graph(oracle, synth, pkg, gpu):
 
 
 def _soak_cases():
+    """14 cases by default; PVV_SOAK_CASES=N draws the first N of the same sequence (a long run after kernel changes:
+    `PVV_SOAK_CASES=300 pytest tests/test_gpu_parity.py -k soak`)."""
     rng = np.random.RandomState(2026)
     cases = []
-    for i in range(14):
+    for i in range(int(os.environ.get("PVV_SOAK_CASES", "14"))):
         cases.append(dict(H=int(rng.choice([48, 96, 130, 200])), W=int(rng.choice([64, 100, 160, 257])),
                           K=int(rng.choice([1, 2, 5, 9, 17])), hn=int(rng.choice([32, 33, 64, 200, 512, 1000])),
                           thresh=float(rng.choice([0.6, 0.9, 0.99, 0.995, 0.999, 0.9999])),
@@ -723,6 +727,8 @@ def test_randomized_soak_all_counts_bit_exact(oracle, synth, pkg, gpu, case):
     tn = [int(x) for x in (mask != 0).sum((1, 2))]
     if min(tn) < 5:
         pytest.skip("degenerate synthetic mask")
+    if max(tn) > 30000:
+        pytest.skip("subsampled case: covered by test_full_hd_frame_with_subsampling (needs injected selection draws)")
     idxs = synth.make_idxs(tn, hn, c["K"], seed=seed)
     mean = torch.zeros(c["B"], c["K"], 2)
     det = []
