@@ -14,11 +14,14 @@
 // pieces x = x0 + x1 + x2 (+ <= 2^-27 |x|), the six leading piece products of hx*nhx and of hy*nhy plus the three
 // pieces of the constant are the 15 terms of a K=16 dot product, and ONE v_mfma_f32_32x32x16_bf16 delivers a
 // (rows 0-15) and b' (rows 16-31) for 16 pixels x 32 hypotheses.  The VALU keeps t = a - |b'|, the sign-bit
-// queue and the guard-band measure: 29 instructions per 512 evaluations instead of 56 x 4.
+// queue and the guard-band test: 21 instructions per 512 evaluations instead of 56 x 4.
 //
 // The MFMA result is only a PREFILTER: the decision is taken from it when |t| - beta*a > eps, otherwise that
-// evaluation is redone with the exact binary32 sequence (K:100-125).  Bound, with u = 2^-24, d = fl(h-c) as the
-// exact path sees it, o = the block's integer origin, c' = c-o (exact), h' = fl(h-o), C1 = max |c'|_1 of the block:
+// evaluation is redone with the exact binary32 sequence (K:100-125).  The hot loop tests a whole 16x32 tile against
+// a per-hypothesis upper bound of beta*a + eps (one v_min3 chain); tiles that fail mark their in-band evaluations
+// while a and t are in registers, and only those are re-decided after the 8 tiles of the hypothesis tile.
+// Bound, with u = 2^-24, d = fl(h-c) as the exact path sees it, o = the block's integer origin, c' = c-o (exact),
+// h' = fl(h-o), C1 = max |c'|_1 of the block:
 //     piece residuals and dropped piece products          <= 0.5 u S,   S = |hx' nhx| + |hy' nhy| + |c'.nh|
 //     bf16 MFMA accumulation (products exact in f32; 15 f32 roundings in any order)  <= 15 u S
 //     (measured on MI355X: 3.9 u S including the split, bf16_mfma_overlap.hip)
