@@ -744,6 +744,41 @@ def test_randomized_soak_all_counts_bit_exact(oracle, synth, pkg, gpu, case):
     np.testing.assert_allclose(_np(out), want, rtol=1e-6, atol=ATOL)
 
 
+def test_foreground_sizes_around_tile_and_chunk_edges(oracle, pkg, gpu):
+    """The count kernel cuts an image's tn compacted pixels into 512-pixel chunks and 16-pixel tiles that go round-robin
+    to 4 waves, skipping empty tiles: tn just below / at / above every boundary (and one pixel over a chunk), all
+    B*K*hn counts bit-exact, means within 1e-4."""
+    from clean_pvnet_amd import ransac_voting as ext
+    sizes = [5, 15, 16, 17, 31, 33, 63, 64, 65, 127, 128, 129, 255, 257, 511, 512, 513, 527, 529, 1023, 1024, 1025, 1537]
+    B, H, W, K, hn = len(sizes), 40, 48, 3, 96
+    g = torch.Generator().manual_seed(31)
+    mask = torch.zeros(B, H, W, dtype=torch.int64)
+    for i, n in enumerate(sizes):
+        mask[i].view(-1)[torch.randperm(H * W, generator=g)[:n]] = 1
+    vertex = torch.randn(B, H, W, K, 2, generator=g)
+    # aim most directions at a common point so that counts are far from 0 and from tn
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    for k in range(K):
+        d = torch.stack([10.0 + 9 * k - xs, 20.0 - ys], -1)
+        d = d / d.norm(dim=-1, keepdim=True).clamp(min=1e-3)
+        keep = torch.rand(B, H, W, generator=g) < 0.7
+        vertex[:, :, :, k] = torch.where(keep[..., None], d + 0.03 * torch.randn(B, H, W, 2, generator=g), vertex[:, :, :, k])
+    idxs = torch.zeros(B, hn, K, 2, dtype=torch.int32)
+    for i, n in enumerate(sizes):
+        idxs[i] = torch.randint(0, n, (hn, K, 2), generator=g, dtype=torch.int32)
+    mean = torch.zeros(B, K, 2)
+    det = []
+    oracle.estimate_voting_distribution_with_mean(_np(mask), _np(vertex), _np(mean), hn, hn, inlier_thresh=0.99, idxs=_np(idxs),
+                                                  details=det)
+    cov, hyp, counts, tnn = capi.estimate(mask.to(gpu), vertex.to(gpu), mean.to(gpu), hn, 0.99, idxs=idxs.to(gpu))
+    assert _np(tnn).tolist() == sizes
+    for bi in range(B):
+        np.testing.assert_array_equal(_np(counts[bi]), det[bi]["counts"].T, err_msg="tn = %d" % sizes[bi])
+    out, win, _t, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), hn, 0.99, 5, 30000, idxs.to(gpu), None, 0, ext.SINGULAR_ZERO)
+    want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, 0.99, idxs=_np(idxs), singular="zero")
+    np.testing.assert_allclose(_np(out), want, rtol=1e-6, atol=ATOL)
+
+
 def test_batches_beyond_1024_images_are_split_by_the_python_layer(oracle, pkg, gpu):
     """The count kernels keep their work-item table in LDS (<= 1024 images per launch, PVV_E_ARG beyond); the Python
     layers split larger batches.  1030 tiny images, three of them checked against the oracle."""
