@@ -237,8 +237,17 @@ int launch_count_fast(const pvv_problem *p, const Layout &L, char *ws, hipStream
 
 int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st)
 {
-    static const int per_cu = env_int("PVV_GRID_PER_CU", 24);
+    // persistent blocks per CU (5 are resident): every block builds the item table once, so few blocks are better when
+    // items are short (hn <= 512: one hypothesis group per item), more when they are long and uneven; several
+    // generations of blocks also stagger the latency-bound prologues against the VALU-bound loops (exactly 5 per CU
+    // runs them in lockstep: +11 %).  Measured on MI355X: 15 vs 24 per CU = -2 % at cfg3 (B = 64) and -20 % at B = 1;
+    // 48 vs 24 = -1 % at cfg5 (2048 hypotheses).  A single atomic work queue instead of the static round-robin was
+    // 12-150 % slower: device-scope atomics on one address serialise at ~20 ns each; an effective grid that gives every
+    // block the same NUMBER of items was 6 % slower too -- its stride (32 images' worth of items) lines the near-empty
+    // last chunks of all images up in the same blocks.
+    static const int per_cu_env = env_int("PVV_GRID_PER_CU", 0);
     static const int items_per_cu = env_int("PVV_ITEMS_PER_CU", 2);
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (p->hn <= 512 ? 15 : 48);
     hipLaunchKernelGGL(k_count_bf16, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, (const float2 *)(ws + L.coords),
                        (const float2 *)(ws + L.dirs), (const float2 *)(ws + L.hyps), (int *)(ws + L.counts),
                        (const int *)(ws + L.tn), p->B, p->K, p->hn, p->cap, p->inlier_thresh,
