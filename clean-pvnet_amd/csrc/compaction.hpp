@@ -19,6 +19,7 @@ struct MaskArgs {
     uint64_t seed;
     int b0;                  // first_image: RNG key offset of image 0
     int *tn_user;            // the caller's tn[B] (or nullptr): written beside the workspace copy, no D2D copy later
+    int fuse_sub;            // 1: k_compact applies the subsampling itself (no k_tile_subsample launch), see there
     // fused argmax (decode_keypoint): when seg != nullptr the mask value is argmax_c seg[b,c,y,x]
     const float *seg;
     long long *mask_out;     // [B,H,W] int64 or nullptr
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
     const int t = blockIdx.x, b = blockIdx.y;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
 
-    if (t != 0 && tile_nz[b * a.T + t] == 0) return;  // background-only tile: nothing to scatter
+    // background-only tile: nothing to scatter (tile 0 reports tn; with fused subsampling the last tile does)
+    if (t != 0 && !(a.fuse_sub && t == a.T - 1) && tile_nz[b * a.T + t] == 0) return;
 
     // this tile's foreground map, requested before the reductions below so that the two latencies overlap
     const unsigned long long *wb = bits + ((size_t)b * a.T + t) * (kTileSteps * 4);
@@ -237,7 +239,33 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
         }
         return;
     }
-    if (t == 0 && threadIdx.x == 0) {
+    // P:135-138 / P:219-223 fused (images of <= kFuseSubTiles tiles; larger ones go through k_tile_subsample first):
+    // when foreground_num > max_num every foreground pixel survives with probability max_num/foreground_num.  The
+    // draws are keyed by (image, pixel), so this block redoes them for its own tile AND for the tiles before it -- it
+    // needs their survivor counts for its row offset.  Rare and bounded (<= kFuseSubTiles tiles), and it saves a launch
+    // on every call; the last tile's block reports tn.
+    const bool sub = a.fuse_sub && fg > (long long)a.max_num;
+    if (sub) {
+        const float prob = (float)a.max_num / (float)fg;
+        int cnt = 0;
+        for (int i = 0; i < t; ++i) {
+            if (tile_nz[b * a.T + i] == 0) continue;                       // block-uniform
+            const unsigned long long *wi = bits + ((size_t)b * a.T + i) * (kTileSteps * 4);
+#pragma unroll
+            for (int s = 0; s < kTileSteps; ++s) {
+                const bool f = (wi[s * 4 + wave] >> lane) & 1ull;
+                if (f) cnt += selection_draw(a, b, i * kTile + s * kBlock + threadIdx.x) < prob ? 1 : 0;
+            }
+        }
+        __syncthreads();                                                   // red[] was read above
+        before = block_sum(cnt, red);
+#pragma unroll
+        for (int s = 0; s < kTileSteps; ++s) {
+            bool f = (word[s] >> lane) & 1ull;
+            if (f) f = selection_draw(a, b, t * kTile + s * kBlock + threadIdx.x) < prob;
+            word[s] = __ballot(f);
+        }
+    } else if (t == 0 && threadIdx.x == 0) {
         tn_out[b] = total < a.cap ? total : a.cap;
         if (a.tn_user) a.tn_user[b] = tn_out[b];
     }
@@ -255,6 +283,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
             if (lane >= o) inc += n;
         }
         if (threadIdx.x < kTileSteps * 4) seg[threadIdx.x] = inc - c;
+        if (threadIdx.x == kTileSteps * 4 - 1) seg[kTileSteps * 4] = inc;   // foreground pixels of the tile (after subsampling)
     }
     __syncthreads();
 
@@ -268,7 +297,12 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
         list[lr] = (unsigned short)(s * kBlock + threadIdx.x);
     }
     __syncthreads();
-    const int tile_n = tile_nz[b * a.T + t];
+    const int tile_n = seg[kTileSteps * 4];
+    if (sub && t == a.T - 1 && threadIdx.x == 0) {                       // the last tile knows the subsampled total
+        const int all = before + tile_n;
+        tn_out[b] = all < a.cap ? all : a.cap;
+        if (a.tn_user) a.tn_user[b] = tn_out[b];
+    }
     const int room = a.cap - before;                                     // rows left in the image's list
     const int n = tile_n < room ? tile_n : (room > 0 ? room : 0);
     for (int i = threadIdx.x; i < n; i += kBlock) {

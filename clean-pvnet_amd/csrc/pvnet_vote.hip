@@ -30,6 +30,11 @@ namespace {
 constexpr int kBlock = 256;          // 4 wavefronts
 constexpr int kTileSteps = 8;
 constexpr int kTile = kBlock * kTileSteps;  // pixels per compaction tile
+// Images of up to this many 2048-pixel tiles (480x640 = 150) subsample inside k_compact: one launch less on every call
+// (-3 % at B = 64, -5 % at B = 1 on MI355X).  When subsampling does trigger, every block redoes the draws of the tiles
+// before it, a cost that grows with the square of the tile count: at 190 tiles (540x720, BASELINE config 5, whose
+// 31 k foreground pixels ARE subsampled) it already outweighs the launch (+2 %), so larger images keep k_tile_subsample.
+constexpr int kFuseSubTiles = 160;
 constexpr int kPixPerWave = 64;      // pixels one wave walks per work item of the exact count kernel
 
 thread_local char g_err[512] = "";
@@ -290,8 +295,10 @@ int launch_compaction(const MaskArgs &m, const VertexArgs &v, const Layout &L, c
     unsigned long long *bits = (unsigned long long *)(ws + L.bits);
     hipLaunchKernelGGL(k_tile_count<ES>, grid, block, 0, st, m, tile_nz, tile_sum, bits);
     if (int e = check_launch("k_tile_count")) return e;
-    hipLaunchKernelGGL(k_tile_subsample, grid, block, 0, st, m, tile_nz, (const int *)tile_sum, bits);
-    if (int e = check_launch("k_tile_subsample")) return e;
+    if (!m.fuse_sub) {   // large images only: k_compact would redo too many draws (see there)
+        hipLaunchKernelGGL(k_tile_subsample, grid, block, 0, st, m, tile_nz, (const int *)tile_sum, bits);
+        if (int e = check_launch("k_tile_subsample")) return e;
+    }
     hipLaunchKernelGGL(k_compact, grid, block, 0, st, m, v, (const int *)tile_nz, (const int *)tile_sum,
                        (const unsigned long long *)bits, (int *)(ws + L.tn), (float2 *)(ws + L.coords),
                        (float2 *)(ws + L.dirs), (PixelRec *)(ws + L.recs));
@@ -319,6 +326,7 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
     m.seed = p->seed;
     m.b0 = p->first_image;
     m.tn_user = d_tn;
+    m.fuse_sub = L.T <= kFuseSubTiles ? 1 : 0;
     VertexArgs v;
     v.vertex = d_vertex;
     v.sb = p->vertex_stride[0]; v.sh = p->vertex_stride[1]; v.sw = p->vertex_stride[2];

@@ -322,6 +322,28 @@ def test_v3_subsample_with_injected_selection(oracle, synth, pkg, gpu):
     assert np.abs(_np(out_r) - _np(d["kpt_2d"])).max() < 6.0
 
 
+def test_v3_subsample_fused_into_compaction_at_480x640(oracle, synth, pkg, gpu):
+    """480x640 = 150 tiles: the subsampling of P:135-138 happens inside k_compact (no k_tile_subsample launch), every
+    block redoing the draws of the tiles before it.  ~12 % foreground (37 k pixels > max_num = 30000), injected draws:
+    tn, every count and the means must equal the oracle's; the second image (2 % foreground) is not subsampled."""
+    from clean_pvnet_amd import ransac_voting as ext
+    d0 = synth.make_batch(B=1, H=480, W=640, K=2, fg=0.12, sigma=0.05, seed=77)
+    d1 = synth.make_batch(B=1, H=480, W=640, K=2, fg=0.02, sigma=0.05, seed=78)
+    mask, vertex = torch.cat([d0["mask"], d1["mask"]]), torch.cat([d0["vertex"], d1["vertex"]])
+    selection = torch.rand(mask.shape, generator=torch.Generator().manual_seed(8))
+    fg = mask.sum((1, 2)).float()
+    assert float(fg[0]) > 30000 > float(fg[1])
+    prob = (torch.tensor(30000.0) / fg).view(-1, 1, 1)
+    kept = (mask != 0) & ((fg <= 30000).view(-1, 1, 1) | (selection < prob))
+    tn = [int(x) for x in kept.sum((1, 2))]
+    hn = 64
+    idxs = synth.make_idxs(tn, hn, 2, seed=77)
+    out, win, tnn, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), hn, 0.99, 5, 30000, idxs.to(gpu), selection.to(gpu), 0,
+                                              ext.SINGULAR_REFERENCE)
+    assert _np(tnn).tolist() == tn
+    _check_v3(oracle, out, win, tnn, mask, vertex, idxs, hn, 0.99, selection=selection, max_num=30000)
+
+
 # --------------------------------------------------------------------------------------------------
 # estimate_voting_distribution_with_mean
 # --------------------------------------------------------------------------------------------------
