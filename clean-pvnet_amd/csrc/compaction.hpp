@@ -310,9 +310,9 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
         const int y = p / a.W;
         coords[(size_t)b * a.cap + before + i] = make_float2((float)(p - y * a.W), (float)y);
     }
-    // n*K gathers of 8 bytes each; four per thread in flight (all loads of a trip before its stores), otherwise every
+    // n*K gathers of 8 bytes each; eight per thread in flight (all loads of a trip before its stores), otherwise every
     // trip of the loop pays a full memory latency: 9 trips at K = 9 and ~250 foreground pixels per tile
-    constexpr int kGather = 4;
+    constexpr int kGather = 8;
     const int total_g = n * v.K;
     for (int i0 = threadIdx.x; i0 < total_g; i0 += kGather * kBlock) {
         float2 d[kGather];
