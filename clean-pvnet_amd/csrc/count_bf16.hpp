@@ -264,19 +264,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                             if (__builtin_expect(__ballot(tmin <= wband) != 0, 0)) {
                                 // rare (a few % of the tiles): mark the evaluations that really are inside the band,
                                 // |t| - beta a <= eps, while a and t are still in registers; they are re-decided below
-                                unsigned m = 0u;
+                                // (sign bit of eps - z is set exactly when z > eps: the same bit queue as for t, 3 VALU per
+                                // evaluation; evaluation e of the tile ends up in bit 7 - e, set = NOT in the band)
+                                unsigned out_of_band = 0u;
 #pragma unroll
                                 for (int e = 0; e < 8; ++e)
-                                    m |= (__builtin_fmaf(-fc.beta, acc[e], fabsf(t[e])) <= eps) ? (1u << e) : 0u;
-                                mb[j >> 2] |= m << (8 * (j & 3));
+                                    out_of_band = __builtin_amdgcn_alignbit(
+                                        out_of_band, __float_as_uint(eps - __builtin_fmaf(-fc.beta, acc[e], fabsf(t[e]))), 31);
+                                mb[j >> 2] |= (~out_of_band & 0xffu) << (8 * (j & 3));
                                 flagged |= 1u << j;
                             }
                         }
                     }
                     int inl = 8 * ntile_w - __popc(qs[0]) - __popc(qs[1]);   // sign bit set = not an inlier
-                    if (__builtin_expect(flagged != 0u, 0)) {
-                        // (loading the un-translated hypothesis here, not ahead of the tiles: the prefetch costs more issue
-                        // slots in every iteration than the stall does in every third, measured +1.6 %)
+                    // flagged tiles (a third of the iterations has one) mostly hold no evaluation that really is in the band;
+                    // only then the un-translated hypothesis is fetched (not ahead of the tiles either: that prefetch costs
+                    // more issue slots in every iteration than the stall does in a sixth of them, measured +1.6 %)
+                    if (__builtin_expect(flagged != 0u, 0) && __any((mb[0] | mb[1]) != 0u)) {
                         const int h = (ht0 + ht) * 32 + col;
                         const float2 hp = h < hn ? hyp_k[h] : make_float2(0.f, 0.f);
                         do {
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                             const unsigned sgn = qs[j >> 2] >> (8 * after);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                const bool marked = (m >> e) & 1u;
+                                const bool marked = (m >> (7 - e)) & 1u;
                                 if (!__any(marked)) continue;
                                 const int prow = (j * 4 + wave) * 16 + ebase + (e & 3) + 8 * (e >> 2);
                                 const int p = pb + prow;
