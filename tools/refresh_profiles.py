@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Copy the judged summaries of one gpurun profiling session into profiles/ (round tag r01):
+    python tools/refresh_profiles.py gpurun_out/prof_<tag> gpurun_out/<dir with bench_default.json, bench_extras.json>
+The session is produced on the GPU box by tools/profile_bench.sh <tag> plus `python bench.py [--extras]`."""
+import csv, glob, json, os, re, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prof, fin = sys.argv[1], sys.argv[2]
+tmp = os.path.join(ROOT, "profiles", "r01_summary.json")
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_prof.py"), prof, "--json", tmp],
+                      stdout=subprocess.DEVNULL)
+
+
+def short(n):
+    m = re.search(r"(k_[a-z_0-9]+(<\d+>)?)", n)
+    return m.group(1) if m else None
+
+
+rows = list(csv.DictReader(open(glob.glob(os.path.join(prof, "trace", "*kernel_stats.csv"))[0])))
+with open(os.path.join(ROOT, "profiles", "r01_kernel_stats.csv"), "w") as o:
+    w = csv.writer(o)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
+    for r in rows:
+        if short(r["Name"]):
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+summ = json.load(open(tmp))
+p = summ["pmc"]["k_count_bf16"]
+pmc_path = os.path.join(ROOT, "profiles", "count_kernel_pmc.json")
+old = json.load(open(pmc_path))
+fetch, write = p["FETCH_SIZE"]["main_mean"], p["WRITE_SIZE"]["main_mean"]
+old.update({"FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "hbm_bytes_per_launch": int((fetch + write) * 1024),
+            "images_per_launch": 64,
+            "source": "%s (tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, python "
+                      "bench.py --steps 20 --warmup 5 --no-cpu-baseline), final tree of round 1" % prof})
+json.dump(old, open(pmc_path, "w"), indent=1)
+for a, b in (("bench_default", "r01_bench_default"), ("bench_extras", "r01_bench_extras")):
+    line = [l for l in open(os.path.join(fin, a + ".json")) if l.startswith("{")][-1]
+    json.dump(json.loads(line), open(os.path.join(ROOT, "profiles", b + ".json"), "w"), indent=1)
+k = summ["kernel_stats"]
+g = p["GRBM_GUI_ACTIVE"]["main_mean"] / 8
+print("k_count_bf16 avg_us %.2f  VALU insts %.3g  VALU busy %.3f  clock GHz %.2f" % (
+    k["k_count_bf16"]["avg_us"], p["SQ_INSTS_VALU"]["main_mean"], p["SQ_ACTIVE_INST_VALU"]["main_mean"] * 4 / 1024 / g,
+    g / (k["k_count_bf16"]["avg_us"] * 1e3)))
+for n, v in k.items():
+    print("  %-20s %8.2f us" % (n, v["avg_us"]))
