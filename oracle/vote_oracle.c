@@ -5,11 +5,16 @@
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library, and only as the checker / the timed CPU baseline.
  *
- * PARITY STATUS: "parity unpinned" by the reference's own tests -- the
- * reference ships no tests, golden vectors or CPU implementation for this
- * path, and its CUDA sources cannot be built here.
- * The kernels below restate the .cu sources line by line; the Python glue
- * restated in vote_oracle.py is additionally pinned against the reference's
+ * PARITY STATUS: pinned against outputs of the reference itself.  The reference
+ * ships no tests, golden vectors or CPU implementation for this path
+ *  and its build (nvcc, torch-1.1 ATen) does not exist here,
+ * but its kernels are four self-contained __global__ functions: oracle/_ref is
+ * the reference's own ransac_voting_kernel.cu, compiled where it lies with hipcc
+ * for gfx950 through the shim headers of oracle/ref_shim/ (oracle/ref_build.hip,
+ * `make -C oracle _ref`) and run on the MI355X through its own launchers.
+ * tests/test_ref_pin.py checks the kernels below against it bit for bit
+ * (hypotheses, inlier bytes, the vanishing-point pair; hostile inputs included).
+ * The Python glue restated in vote_oracle.py is pinned against the reference's
  * own ransac_voting_gpu.py executed on CPU (tests/golden/make_golden.py).
  *
  * Arithmetic contract: IEEE-754 binary32, one rounding per source-level

@@ -4,12 +4,14 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this module, and only as the checker / timed CPU baseline.  The
 product (``clean-pvnet_amd/``) never imports it and has no CPU fallback.
 
-PARITY STATUS: *parity unpinned* by the reference's own tests (it has none for
-this path).  What pins this oracle instead:
+PARITY STATUS: pinned against outputs of the reference itself (it has no tests
+of its own for this path):
 
-* the two kernels are line-by-line restatements of
-  ``lib/csrc/ransac_voting/src/ransac_voting_kernel.cu`` (C in
-  ``vote_oracle.c``, numpy twins below, cross-checked against each other);
+* the kernels (C in ``vote_oracle.c``, numpy twins below, cross-checked against
+  each other) are checked bit for bit against ``oracle/_ref`` -- the reference's
+  own ``lib/csrc/ransac_voting/src/ransac_voting_kernel.cu``, compiled where it
+  lies with hipcc for gfx950 through ``oracle/ref_shim/`` and run on the MI355X
+  through its own launchers (``oracle/ref_build.hip``, ``tests/test_ref_pin.py``);
 * the Python glue (select / refit / covariance) is checked against the
   reference's own ``ransac_voting_gpu.py`` executed on CPU tensors with these
   kernels substituted for the CUDA extension (``tests/golden/make_golden.py``

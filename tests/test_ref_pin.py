@@ -1,0 +1,204 @@
+"""The pin of the oracle: the reference's OWN kernels, run on the MI355X.
+
+``oracle/_ref/libref_ransac_voting.so`` is /root/reference/lib/csrc/ransac_voting/src/ransac_voting_kernel.cu, compiled
+where it lies with hipcc for gfx950 through the shim headers of ``oracle/ref_shim/`` (``oracle/ref_build.hip``,
+``make -C oracle _ref``; built by ``__graft_entry__.build()`` in the container that has the reference and shipped to the
+GPU box as a prebuilt file).  Its four kernels run through the reference's own launchers (launch shapes, zero-filled
+outputs).  Checked here, bit for bit:
+
+  * the oracle's C restatement (what every other parity test compares against) == the reference's kernels,
+  * the product's module-level kernels == the reference's kernels (no oracle in between),
+  * the product's fused inlier count == the sum over the reference's inlier bytes,
+
+on seeded fields, degenerate pairs, non-finite directions, pixels on a hypothesis, thresholds from 0.5 to 0.9999, and on
+the golden fixtures' inputs.  ``libref_ransac_voting_fma.so`` is the same file with floating-point contraction allowed
+(nvcc's default): the test records how few decisions that changes.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import capi
+
+pytestmark = pytest.mark.gpu
+
+REF_DIR = os.path.join(capi.ROOT, "oracle", "_ref")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _same_floats(a, b):
+    """bit patterns equal; a NaN equals a NaN (x86 and gfx950 disagree on the sign bit of a generated NaN)"""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    nan = np.isnan(a)
+    np.testing.assert_array_equal(nan, np.isnan(b))
+    np.testing.assert_array_equal(np.where(nan, 0, a.view(np.uint32)), np.where(nan, 0, b.view(np.uint32)))
+
+
+def _load(name):
+    path = os.path.join(REF_DIR, name)
+    if not os.path.exists(path):
+        pytest.fail("%s is missing: run `python __graft_entry__.py` (build()) where /root/reference is mounted; the file "
+                    "travels to the GPU box with the tree" % path)
+    L = ctypes.CDLL(path)
+    vp, i32, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    L.ref_generate_hypothesis.argtypes = [vp, vp, vp, vp, i32, i32, i32]
+    L.ref_generate_hypothesis_vanishing_point.argtypes = [vp, vp, vp, vp, i32, i32, i32]
+    L.ref_voting_for_hypothesis.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32]
+    L.ref_voting_for_hypothesis_vanishing_point.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32]
+    return L
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return _load("libref_ransac_voting.so")
+
+
+class Ref:
+    """the reference's kernels on torch CUDA tensors (reference layouts: direct [tn,vn,2], coords [tn,2], idxs [hn,vn,2])"""
+
+    def __init__(self, L):
+        self.L = L
+
+    def generate(self, direct, coords, idxs, vp=False):
+        tn, vn, _ = direct.shape
+        hn = idxs.shape[0]
+        out = torch.full((hn, vn, 3 if vp else 2), float("nan"), device=direct.device)
+        f = self.L.ref_generate_hypothesis_vanishing_point if vp else self.L.ref_generate_hypothesis
+        torch.cuda.synchronize()
+        assert f(capi.ptr(direct), capi.ptr(coords), capi.ptr(idxs), capi.ptr(out), tn, vn, hn) == 0
+        return out
+
+    def vote(self, direct, coords, hypo, thresh, vp=False, fill=0):
+        tn, vn, _ = direct.shape
+        hn = hypo.shape[0]
+        inl = torch.full((hn, vn, tn), fill, dtype=torch.uint8, device=direct.device)
+        f = self.L.ref_voting_for_hypothesis_vanishing_point if vp else self.L.ref_voting_for_hypothesis
+        torch.cuda.synchronize()
+        assert f(capi.ptr(direct), capi.ptr(coords), capi.ptr(hypo), capi.ptr(inl), tn, vn, hn, thresh) == 0
+        return inl
+
+
+def _field(oracle, synth, cfg, seed, **over):
+    d = synth.make_batch(**{**synth.CONFIGS[cfg], **over, "B": 1}, seed=seed)
+    _fg, coords, direct = oracle.compact_v3(_np(d["mask"][0]), _np(d["vertex"][0]))
+    return coords, direct
+
+
+def _idxs(tn, hn, vn, seed):
+    g = np.random.RandomState(seed).randint(0, tn, size=(hn, vn, 2)).astype(np.int32)
+    g[0, :, 1] = g[0, :, 0]                     # t0 == t1: degenerate pair -> (0,0), still voted on
+    return g
+
+
+CASES = [("cfg1", 64, 0.99, 11, {}), ("cfg1", 200, 0.5, 12, {}), ("cfg1", 33, 0.9999, 13, {"sigma": 0.0}),
+         ("cfg2", 128, 0.99, 14, {}), ("cfg2", 64, 0.999, 15, {"sigma": 0.3}), ("cfg1", 1, 0.9, 16, {"K": 1})]
+
+
+@pytest.mark.parametrize("cfg,hn,thresh,seed,over", CASES)
+def test_oracle_and_product_equal_the_reference_kernels(oracle, synth, pkg, gpu, ref, cfg, hn, thresh, seed, over):
+    from clean_pvnet_amd import ransac_voting as ext
+    R = Ref(ref)
+    coords, direct = _field(oracle, synth, cfg, seed, **over)
+    tn, vn, _ = direct.shape
+    # hostile values the reference code meets in the wild: zero / tiny / huge / non-finite directions, parallel pairs
+    rng = np.random.RandomState(seed)
+    for j, val in enumerate([(0.0, 0.0), (1e-7, -1e-7), (np.inf, 1.0), (np.nan, 0.5), (3e19, -3e19), (1e-30, 1e-30)]):
+        direct[rng.randint(0, tn), rng.randint(0, vn)] = val
+    direct[5 % tn] = direct[3 % tn]                                   # parallel lines through two pixels
+    idxs = _idxs(tn, hn, vn, seed)
+    idxs[min(1, hn - 1), :, 0], idxs[min(1, hn - 1), :, 1] = 3 % tn, 5 % tn
+    d, c, i = torch.from_numpy(direct).to(gpu), torch.from_numpy(coords).to(gpu), torch.from_numpy(idxs).to(gpu)
+
+    # --- hypotheses: reference kernel == oracle == product (bit patterns, NaNs included)
+    ref_h = R.generate(d, c, i)
+    want_h = oracle.generate_hypothesis(direct, coords, idxs)
+    got_h = ext.generate_hypothesis(d, c, i)
+    _same_floats(_np(ref_h), want_h)
+    _same_floats(_np(got_h), _np(ref_h))
+    # a hypothesis exactly on a pixel (norm2 = 0 -> never an inlier there)
+    ref_h[hn - 1, 0] = c[7 % tn]
+    hyp_np = _np(ref_h)
+
+    # --- inlier bytes: reference kernel == oracle == product; the reference never writes 0
+    ref_inl = R.vote(d, c, ref_h, thresh)
+    want_inl = oracle.voting_for_hypothesis(direct, coords, hyp_np, np.zeros((hn, vn, tn), np.uint8), thresh)
+    np.testing.assert_array_equal(_np(ref_inl), want_inl)
+    got_inl = torch.zeros(hn, vn, tn, dtype=torch.uint8, device=gpu)
+    ext.voting_for_hypothesis(d, c, ref_h, got_inl, thresh)
+    assert torch.equal(got_inl, ref_inl)
+    np.testing.assert_array_equal(_np(R.vote(d, c, ref_h, thresh, fill=7)), np.where(want_inl == 1, 1, 7))
+
+    # --- the product's fused count (every count kernel variant is tested against this path elsewhere) == sum of the
+    #     reference's bytes
+    counts = ext.count_inliers(d, c, ref_h, thresh)
+    assert torch.equal(counts.to(torch.int64), ref_inl.to(torch.int64).sum(2))
+
+
+def test_vanishing_point_pair_equals_the_reference_kernels(oracle, synth, pkg, gpu, ref):
+    from clean_pvnet_amd import ransac_voting as ext
+    R = Ref(ref)
+    coords, direct = _field(oracle, synth, "cfg1", 21)
+    tn, vn, _ = direct.shape
+    hn = 80
+    idxs = _idxs(tn, hn, vn, 21)
+    d, c, i = torch.from_numpy(direct).to(gpu), torch.from_numpy(coords).to(gpu), torch.from_numpy(idxs).to(gpu)
+    ref_h = R.generate(d, c, i, vp=True)
+    _same_floats(_np(ref_h), oracle.generate_hypothesis_vanishing_point(direct, coords, idxs))
+    _same_floats(_np(ext.generate_hypothesis_vanishing_point(d, c, i)), _np(ref_h))
+    for thresh in (0.99, 0.6):
+        ref_inl = R.vote(d, c, ref_h, thresh, vp=True)
+        want = oracle.voting_for_hypothesis_vanishing_point(direct, coords, _np(ref_h), np.zeros((hn, vn, tn), np.uint8), thresh)
+        np.testing.assert_array_equal(_np(ref_inl), want)
+        got = torch.zeros(hn, vn, tn, dtype=torch.uint8, device=gpu)
+        ext.voting_for_hypothesis_vanishing_point(d, c, ref_h, got, thresh)
+        assert torch.equal(got, ref_inl)
+        assert int(ref_inl.sum()) > 0
+
+
+def test_whole_layer_on_reference_kernels_equals_the_batched_product(oracle, synth, pkg, gpu, ref):
+    """ransac_voting_layer_v3 rebuilt around the REFERENCE's kernels (compaction and the torch glue as in P:140-167:
+    nonzero order, sum over tn, first maximum) against one call of the batched product on the same draws: hypotheses
+    and the winning counts bit-exact."""
+    from clean_pvnet_amd import ransac_voting as ext
+    R = Ref(ref)
+    d0 = synth.make_batch(**{**synth.CONFIGS["cfg1"], "B": 3}, seed=31)
+    mask, vertex = d0["mask"].to(gpu), d0["vertex"].to(gpu)
+    B, H, W, K, _ = vertex.shape
+    hn = 96
+    tn = [int(x) for x in (mask != 0).sum((1, 2))]
+    idxs = synth.make_idxs(tn, hn, K, seed=31).to(gpu)
+    out, win, tnn, _ws = ext.ransac_voting_v3(mask, vertex, hn, 0.99, 5, 30000, idxs, None, 0, ext.SINGULAR_REFERENCE)
+    cov, hyp, counts, _t = capi.estimate(mask, vertex, torch.zeros(B, K, 2, device=gpu), hn, 0.99, idxs=idxs)
+    for b in range(B):
+        cur = mask[b] != 0
+        coords = torch.nonzero(cur).float()[:, [1, 0]].contiguous()                    # P:140-141
+        direct = vertex[b][cur].contiguous()                                          # P:142-143  [tn,K,2]
+        ref_h = R.generate(direct, coords, idxs[b].contiguous())
+        ref_cnt = R.vote(direct, coords, ref_h, 0.99).to(torch.int64).sum(2)          # P:155-159  [hn,K]
+        assert torch.equal(hyp[b].permute(1, 0, 2).contiguous().view(torch.int32), ref_h.view(torch.int32))
+        assert torch.equal(counts[b].to(torch.int64).t(), ref_cnt)
+        assert torch.equal(win[b].to(torch.int64), ref_cnt.max(0).values)             # P:160
+
+
+def test_fma_contraction_changes_almost_nothing(oracle, synth, pkg, gpu, ref):
+    """nvcc contracts a*b+c into an FMA by default; SURVEY appendix A (and the oracle) fix the source-level, uncontracted
+    arithmetic.  Same reference file, contraction allowed: count how many inlier decisions and hypotheses move."""
+    fma = Ref(_load("libref_ransac_voting_fma.so"))
+    R = Ref(ref)
+    coords, direct = _field(oracle, synth, "cfg2", 41)
+    tn, vn, _ = direct.shape
+    hn = 256
+    idxs = _idxs(tn, hn, vn, 41)
+    d, c, i = torch.from_numpy(direct).to(gpu), torch.from_numpy(coords).to(gpu), torch.from_numpy(idxs).to(gpu)
+    h0, h1 = R.generate(d, c, i), fma.generate(d, c, i)
+    rel = ((h0 - h1).abs() / h0.abs().clamp(min=1.0)).max().item()
+    assert rel < 1e-3                                           # last-bit differences, amplified by near-parallel pairs
+    a, b = R.vote(d, c, h0, 0.99), fma.vote(d, c, h0, 0.99)
+    flipped = int((a != b).sum())
+    assert flipped <= 1e-5 * a.numel() + 2, flipped             # a handful of decisions among 14 M
