@@ -132,3 +132,18 @@ def test_shard_bounds_cover_batch_exactly(pkg):
             assert spans[0][0] == 0 and spans[-1][1] == batch
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(hi - lo for lo, hi in spans) == -(-batch // world)
+
+
+def test_reference_pin_is_built():
+    """oracle/_ref (the reference's own kernels, compiled through oracle/ref_shim) must exist wherever the reference is
+    mounted -- build() makes it -- and export the four wrappers tests/test_ref_pin.py calls on the GPU."""
+    import ctypes
+    import subprocess
+    if not os.path.exists("/root/reference/lib/csrc/ransac_voting/src/ransac_voting_kernel.cu"):
+        pytest.skip("no /root/reference here: oracle/_ref travels as a prebuilt file")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_ref", "_ref_fma"], stdout=subprocess.DEVNULL)
+    for name in ("libref_ransac_voting.so", "libref_ransac_voting_fma.so"):
+        L = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", name))
+        for sym in ("ref_generate_hypothesis", "ref_voting_for_hypothesis", "ref_generate_hypothesis_vanishing_point",
+                    "ref_voting_for_hypothesis_vanishing_point"):
+            assert hasattr(L, sym), (name, sym)
