@@ -203,3 +203,35 @@ def test_fma_contraction_changes_almost_nothing(oracle, synth, pkg, gpu, ref):
     a, b = R.vote(d, c, h0, 0.99), fma.vote(d, c, h0, 0.99)
     flipped = int((a != b).sum())
     assert flipped <= 1e-5 * a.numel() + 2, flipped             # a handful of decisions among 14 M
+
+
+def test_reference_kernel_timed_on_the_same_gpu(oracle, synth, pkg, gpu, ref, capsys):
+    """Context number for DESIGN.md: the reference's voting_for_hypothesis kernel + torch.sum (what P:155-159 runs per
+    image) against the product's fused count, same image (480x640, K = 9, 512 hypotheses), same MI355X, same result."""
+    from clean_pvnet_amd import ransac_voting as ext
+    R = Ref(ref)
+    coords, direct = _field(oracle, synth, "cfg2", 51)
+    tn, vn, _ = direct.shape
+    hn = 512
+    d, c = torch.from_numpy(direct).to(gpu), torch.from_numpy(coords).to(gpu)
+    h = R.generate(d, c, torch.from_numpy(_idxs(tn, hn, vn, 51)).to(gpu))
+
+    def timed(f, n=20):
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            out = f()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n, out
+
+    t_ref, cnt_ref = timed(lambda: R.vote(d, c, h, 0.99).to(torch.int64).sum(2))     # zeros + kernel + sum, P:155-159
+    t_new, cnt_new = timed(lambda: ext.count_inliers(d, c, h, 0.99))
+    assert torch.equal(cnt_new.to(torch.int64), cnt_ref)
+    with capsys.disabled():
+        print("\n[ref-pin] one 480x640 image, K=9, 512 hyp, tn=%d: reference kernel + sum %.3f ms, fused count %.3f ms (x%.1f)"
+              % (tn, t_ref, t_new, t_ref / t_new))
+    assert t_new < t_ref
