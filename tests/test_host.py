@@ -147,3 +147,4 @@ def test_reference_pin_is_built():
         for sym in ("ref_generate_hypothesis", "ref_voting_for_hypothesis", "ref_generate_hypothesis_vanishing_point",
                     "ref_voting_for_hypothesis_vanishing_point"):
             assert hasattr(L, sym), (name, sym)
+    assert hasattr(ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_nn.so")), "ref_findNearestPointIdxLauncher")

@@ -92,3 +92,36 @@ def test_hip_nearest_neighbour_device_pointers_batched_exclude_self(oracle, pkg,
         want = oracle.find_nearest_point_idx(pts[bi], pts[bi], exclude_self=True)
         np.testing.assert_array_equal(got[bi], want)
         assert (got[bi] != np.arange(pn)).all()                    # a point is never its own neighbour
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,b,pn1,pn2,excl", [(3, 1, 5841, 5841, 0), (3, 2, 700, 300, 0), (2, 1, 1500, 1500, 1), (3, 1, 1, 9, 0),
+                                                (2, 3, 333, 1025, 0)])
+def test_reference_nn_kernel_pins_oracle_and_product(oracle, pkg, gpu, dim, b, pn1, pn2, excl):
+    """oracle/_ref/libref_nn.so = the reference's own lib/csrc/nn/src/nearest_neighborhood.cu, compiled where it lies with
+    hipcc through oracle/ref_shim/ and run on the MI355X through its own launcher (host pointers).  Indices of the
+    reference == oracle == product (same C symbol, same arguments), ties and duplicates included."""
+    path = os.path.join(ROOT, "oracle", "_ref", "libref_nn.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libref_nn.so is built only where /root/reference is mounted (see tests/test_host.py)")
+    R, P = ctypes.CDLL(path), ctypes.CDLL(NNLIB)
+    args = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5
+    R.ref_findNearestPointIdxLauncher.argtypes = args
+    P.findNearestPointIdxLauncher.argtypes = args
+    rng = np.random.RandomState(9)
+    ref = (rng.randn(b, pn1, dim) * 0.05).astype(np.float32)
+    if excl:
+        que = ref.copy()
+    else:
+        que = (ref[:, rng.randint(0, pn1, pn2)] + rng.randn(b, pn2, dim).astype(np.float32) * 0.002).astype(np.float32)
+    if pn1 > 10:
+        ref[:, 7] = ref[:, 3]                                      # exact duplicates: the lower index must win
+        if not excl:
+            que[:, 0] = ref[:, 3]
+    got_ref = np.full((b, pn2), -1, np.int32)
+    got_new = np.full((b, pn2), -2, np.int32)
+    R.ref_findNearestPointIdxLauncher(ref.ctypes.data, que.ctypes.data, got_ref.ctypes.data, b, pn1, pn2, dim, excl)
+    P.findNearestPointIdxLauncher(ref.ctypes.data, que.ctypes.data, got_new.ctypes.data, b, pn1, pn2, dim, excl)
+    np.testing.assert_array_equal(got_new, got_ref)
+    for bi in range(b):
+        np.testing.assert_array_equal(oracle.find_nearest_point_idx(ref[bi], que[bi], exclude_self=bool(excl)), got_ref[bi])
