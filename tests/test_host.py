@@ -148,3 +148,29 @@ def test_reference_pin_is_built():
                     "ref_voting_for_hypothesis_vanishing_point"):
             assert hasattr(L, sym), (name, sym)
     assert hasattr(ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_nn.so")), "ref_findNearestPointIdxLauncher")
+
+
+def test_bench_line_contract_on_the_committed_evidence():
+    """The JSON line bench.py printed on the MI355X (profiles/r01_bench_default.json) carries every field of the driver's
+    contract, the BASELINE.json metric, and numbers that are consistent with each other."""
+    import json
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_default.json")))
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["unit"] == "images/s" and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["metric"].split(" (")[0] in base["metric"] or "images/sec" in base["metric"]
+    r = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) < 1.0
+    assert r["traffic"] is None or 0 < r["traffic"] < r["algorithmic_bytes"]          # no wasted re-reads
+    c = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["unit"] == line["unit"]
+    images = line["config"]["global_batch"] * line["steps"]
+    assert abs(line["value"] - images / (line["ms_per_step"] * 1e-3 * line["steps"])) / line["value"] < 0.01
