@@ -206,7 +206,17 @@ def main():
             def fused():
                 return ext.decode_keypoint_v3(seg, ver.permute(0, 2, 3, 1).view(B, H, W, K, 2), hn, thresh, 5, 30000,
                                               None, None, 7, ext.SINGULAR_REFERENCE)[0]
-            for name, fn in (("decode_unfused_images_per_s", unfused), ("decode_fused_images_per_s", fused)):
+            def un_pnp_two_calls():      # resnet18.py:69-72 as the reference runs it: argmax, v3, estimate
+                vtx = ver.permute(0, 2, 3, 1).view(B, H, W, K, 2)
+                m = torch.argmax(seg, 1)
+                mean = ransac_voting_layer_v3(m, vtx, 512, inlier_thresh=0.99)
+                return estimate_voting_distribution_with_mean(m, vtx, mean)
+
+            def un_pnp_one_pass():       # the same, one mask scan / compaction / hypothesis + count launch
+                return decode_keypoint({"seg": seg, "vertex": ver}, un_pnp=True)["var"]
+            for name, fn in (("decode_unfused_images_per_s", unfused), ("decode_fused_images_per_s", fused),
+                             ("decode_un_pnp_two_calls_images_per_s", un_pnp_two_calls),
+                             ("decode_un_pnp_one_pass_images_per_s", un_pnp_one_pass)):
                 for _ in range(3):
                     fn()
                 torch.cuda.synchronize()

@@ -10,7 +10,8 @@ __global__ __launch_bounds__(kBlock) void k_covariance(
     const int *__restrict__ tn_arr, const float2 *__restrict__ hyps, const int *__restrict__ counts,
     const float2 *__restrict__ mean, float *__restrict__ cov /*[B,K,2,2]*/,
     float2 *__restrict__ hyp_out /*[B,K,hn] or null*/, int *__restrict__ counts_out,
-    float *__restrict__ weights /*[B,K,3] or null*/, int K, int hn)
+    float *__restrict__ weights /*[B,K,3] or null*/, int K, int hn, int hstride /*row length of hyps / counts*/,
+    int hoff /*first hypothesis of the row that belongs to this estimate*/)
 {
     __shared__ int redi[4];
     __shared__ double redd[4];
@@ -18,8 +19,8 @@ __global__ __launch_bounds__(kBlock) void k_covariance(
     const int bk = b * K + vi;
     const int tn = tn_arr[b];
     const float2 m = mean[bk];
-    const float2 *hp = hyps + (size_t)bk * hn;
-    const int *cp = counts + (size_t)bk * hn;
+    const float2 *hp = hyps + (size_t)bk * hstride + hoff;
+    const int *cp = counts + (size_t)bk * hstride + hoff;
     if (hyp_out || counts_out)
         for (int h = threadIdx.x; h < hn; h += kBlock) {
             if (hyp_out) hyp_out[(size_t)bk * hn + h] = tn > 0 ? hp[h] : make_float2(0.f, 0.f);

@@ -8,7 +8,9 @@
 // the inlier counters of the same (b,vi,hi).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_gen_hypothesis(
-    const int32_t *__restrict__ idxs /*[B,hn,K,2] or null*/, const int *__restrict__ tn_arr,
+    const int32_t *__restrict__ idxs /*[B,hn_first,K,2] or null*/, const int32_t *__restrict__ idxs2 /*[B,hn-hn_first,K,2] or null*/,
+    int hn_first /*hypotheses [0,hn_first) draw from idxs, the rest from idxs2 (a layer call: hn_first = hn)*/,
+    const int *__restrict__ tn_arr,
     const float2 *__restrict__ coords, const float2 *__restrict__ dirs, float2 *__restrict__ hyps,
     int *__restrict__ counts, int B, int K, int hn, int cap, uint64_t seed, int b0)
 {
@@ -26,8 +28,10 @@ __global__ __launch_bounds__(kBlock) void k_gen_hypothesis(
         return;
     }
     int t0, t1;
-    if (idxs) {
-        const int32_t *ip = idxs + (((size_t)b * hn + hi) * K + vi) * 2;
+    const int32_t *src = hi < hn_first ? idxs : idxs2;
+    if (src) {
+        const int32_t *ip = hi < hn_first ? idxs + (((size_t)b * hn_first + hi) * K + vi) * 2
+                                          : idxs2 + (((size_t)b * (hn - hn_first) + (hi - hn_first)) * K + vi) * 2;
         t0 = ip[0];
         t1 = ip[1];
         // the reference reads out of bounds here; clamp instead of faulting

@@ -308,7 +308,8 @@ int launch_compaction(const MaskArgs &m, const VertexArgs &v, const Layout &L, c
 // compaction + hypotheses + counting, shared by both layers
 int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d_vertex,
               const int32_t *d_idxs, const float *d_selection, char *ws, const Layout &L,
-              hipStream_t st, int32_t *d_tn, const float *d_seg = nullptr, int64_t *d_mask_out = nullptr)
+              hipStream_t st, int32_t *d_tn, const float *d_seg = nullptr, int64_t *d_mask_out = nullptr,
+              const int32_t *d_idxs2 = nullptr, int hn_first = -1)
 {
     MaskArgs m;
     m.mask = d_mask;
@@ -349,7 +350,8 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
 
     const long long nh = (long long)p->B * p->K * p->hn;
     hipLaunchKernelGGL(k_gen_hypothesis, dim3((unsigned)((nh + kBlock - 1) / kBlock)), dim3(kBlock),
-                       0, st, d_idxs, (const int *)(ws + L.tn), (const float2 *)(ws + L.coords),
+                       0, st, d_idxs, d_idxs2, hn_first < 0 ? p->hn : hn_first, (const int *)(ws + L.tn),
+                       (const float2 *)(ws + L.coords),
                        (const float2 *)(ws + L.dirs), (float2 *)(ws + L.hyps), (int *)(ws + L.counts),
                        p->B, p->K, p->hn, p->cap, p->seed, p->first_image);
     if ((e = check_launch("k_gen_hypothesis"))) return e;
@@ -389,9 +391,12 @@ PVV_EXPORT size_t pvv_workspace_bytes(const pvv_problem *p)
     return make_layout(p).total;
 }
 
+// hstride: row length of hyps / counts in the workspace (= p->hn unless the row also holds the hypotheses of a fused
+// estimate, pvv_decode_keypoint_un_pnp)
 static int finish_v3(const pvv_problem *p, const Layout &L, char *ws, float *d_out, int32_t *d_win_counts,
-                     hipStream_t st)
+                     hipStream_t st, int hstride = 0)
 {
+    if (hstride <= 0) hstride = p->hn;
     // blocks per (keypoint, image): the largest power of two that keeps the grid within ~6 blocks per CU (measured on
     // MI355X: 2 at B*K = 576, 8 for a single image)
     int nsplit = kRefitSplitMax;
@@ -399,7 +404,7 @@ static int finish_v3(const pvv_problem *p, const Layout &L, char *ws, float *d_o
     hipLaunchKernelGGL(k_select_refit, dim3(p->K * nsplit, p->B), dim3(kBlock), 0, st,
                        (const int *)(ws + L.tn), (const float2 *)(ws + L.coords),
                        (const float2 *)(ws + L.dirs), (const float2 *)(ws + L.hyps),
-                       (const int *)(ws + L.counts), (double *)(ws + L.sums), d_win_counts, p->K, p->hn,
+                       (const int *)(ws + L.counts), (double *)(ws + L.sums), d_win_counts, p->K, p->hn, hstride,
                        p->cap, p->inlier_thresh, nsplit);
     if (int e = check_launch("k_select_refit")) return e;
     hipLaunchKernelGGL(k_finalize_v3, dim3(p->B), dim3(64), 0, st, (const int *)(ws + L.tn),
@@ -454,7 +459,53 @@ PVV_EXPORT int pvv_estimate_voting_distribution(const pvv_problem *p, const void
     hipLaunchKernelGGL(k_covariance, dim3(p->K, p->B), dim3(kBlock), 0, st,
                        (const int *)(ws + L.tn), (const float2 *)(ws + L.hyps),
                        (const int *)(ws + L.counts), (const float2 *)d_mean, d_cov, (float2 *)d_hyp,
-                       d_counts, d_weights, p->K, p->hn);
+                       d_counts, d_weights, p->K, p->hn, p->hn, 0);
+    if (int e = check_launch("k_covariance")) return e;
+    return PVV_OK;
+}
+
+// resnet18.py:65-72 with cfg.test.un_pnp as ONE pass (see the header): the row of every (image, keypoint) holds the hn
+// hypotheses of ransac_voting_layer_v3 followed by the hn_est of estimate_voting_distribution_with_mean.
+static pvv_problem un_pnp_problem(const pvv_problem *p, int32_t hn_est)
+{
+    pvv_problem q = *p;
+    q.hn = p->hn + hn_est;
+    return q;
+}
+
+PVV_EXPORT size_t pvv_workspace_bytes_un_pnp(const pvv_problem *p, int32_t hn_est)
+{
+    if (validate(p) || hn_est <= 0) return 0;
+    const pvv_problem q = un_pnp_problem(p, hn_est);
+    if (validate(&q)) return 0;
+    return make_layout(&q).total;
+}
+
+PVV_EXPORT int pvv_decode_keypoint_un_pnp(const pvv_problem *p, int32_t hn_est, const float *d_seg,
+                                          const float *d_vertex, const int32_t *d_idxs, const int32_t *d_idxs_est,
+                                          const float *d_selection, void *d_workspace, size_t workspace_bytes,
+                                          int64_t *d_mask_out, float *d_kpt, float *d_cov, float *d_weights,
+                                          int32_t *d_win_counts, int32_t *d_tn, void *stream)
+{
+    if (int e = validate(p)) return e;
+    if (hn_est <= 0) return fail(PVV_E_ARG, "hn_est must be positive");
+    if (p->mask_elem_size == 0) return fail(PVV_E_ARG, "set mask_elem_size = 8 (the int64 mask this call emits)");
+    // v3 takes `mask != 0` as foreground, the estimate `mask == 1` (P:125 vs P:207): one compaction serves both only
+    // when the argmax cannot produce anything but 0 and 1
+    if (p->seg_classes != 2) return fail(PVV_E_ARG, "the fused un_pnp pass needs seg_classes == 2 (PVNet's seg_dim)");
+    const pvv_problem q = un_pnp_problem(p, hn_est);
+    Layout L;
+    if (int e = check_ptrs(&q, d_seg, d_vertex, d_workspace, workspace_bytes, &L)) return e;
+    if (!d_kpt || !d_cov) return fail(PVV_E_ARG, "d_kpt / d_cov is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)d_workspace;
+    if (int e = run_front(&q, 0, nullptr, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, d_seg, d_mask_out, d_idxs_est,
+                          p->hn))
+        return e;
+    if (int e = finish_v3(p, L, ws, d_kpt, d_win_counts, st, q.hn)) return e;      // mean = winner refit over the first hn
+    hipLaunchKernelGGL(k_covariance, dim3(p->K, p->B), dim3(kBlock), 0, st, (const int *)(ws + L.tn),
+                       (const float2 *)(ws + L.hyps), (const int *)(ws + L.counts), (const float2 *)d_kpt, d_cov,
+                       (float2 *)nullptr, (int *)nullptr, d_weights, p->K, (int)hn_est, q.hn, p->hn);
     if (int e = check_launch("k_covariance")) return e;
     return PVV_OK;
 }

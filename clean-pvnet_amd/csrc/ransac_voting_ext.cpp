@@ -281,6 +281,47 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_v3(
     return {out, mask, win, tn};
 }
 
+// Resnet18.decode_keypoint with cfg.test.un_pnp in one pass (pvv_decode_keypoint_un_pnp): one mask scan, one compaction,
+// one hypothesis + count launch for the round_hyp_num hypotheses of v3 and the hyp_est of the estimate.
+// -> (kpt [b,vn,2], mask [b,h,w] int64, cov [b,vn,2,2], weights [b,vn,3], win_counts [b,vn], tn [b])
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_un_pnp(
+    at::Tensor seg, at::Tensor vertex, int64_t round_hyp_num, int64_t hyp_est, double inlier_thresh, int64_t min_num,
+    int64_t max_num, std::optional<at::Tensor> idxs, std::optional<at::Tensor> idxs_est,
+    std::optional<at::Tensor> selection, int64_t seed, int64_t singular_policy, int64_t first_image)
+{
+    const c10::DeviceGuard device_guard(vertex.device());
+    TORCH_CHECK(seg.is_cuda(), "seg must be a CUDA tensor");
+    TORCH_CHECK(seg.scalar_type() == at::kFloat, "seg must be float32, got ", seg.scalar_type());
+    TORCH_CHECK(seg.dim() == 4 && vertex.dim() == 5 && seg.size(0) == vertex.size(0) && seg.size(2) == vertex.size(1) &&
+                    seg.size(3) == vertex.size(2),
+                "seg must be [b,c,h,w] matching vertex [b,h,w,vn,2]");
+    TORCH_CHECK(hyp_est > 0 && hyp_est < (1 << 24), "hypothesis count of the estimate must be in [1, 2^24)");
+    auto mask = at::empty({seg.size(0), seg.size(2), seg.size(3)}, seg.options().dtype(at::kLong));
+    pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, singular_policy, seed);
+    p.first_image = (int32_t)first_image;
+    p.seg_classes = (int32_t)seg.size(1);
+    for (int i = 0; i < 4; ++i) p.seg_stride[i] = seg.stride(i);
+    const int32_t *ip = opt_idxs(idxs, vertex, p);
+    pvv_problem pe = p;
+    pe.hn = (int32_t)hyp_est;
+    const int32_t *ie = opt_idxs(idxs_est, vertex, pe);
+    const float *sp = opt_selection(selection, vertex, p);
+    const size_t n = pvv_workspace_bytes_un_pnp(&p, (int32_t)hyp_est);
+    TORCH_CHECK(n > 0, "invalid voting problem: ", pvv_last_error());
+    at::Tensor ws = at::empty({(int64_t)n}, vertex.options().dtype(at::kByte));
+    auto kpt = at::empty({p.B, p.K, 2}, vertex.options());
+    auto cov = at::empty({p.B, p.K, 2, 2}, vertex.options());
+    auto weights = at::empty({p.B, p.K, 3}, vertex.options());
+    auto win = at::empty({p.B, p.K}, vertex.options().dtype(at::kInt));
+    auto tn = at::empty({p.B}, vertex.options().dtype(at::kInt));
+    ok(pvv_decode_keypoint_un_pnp(&p, (int32_t)hyp_est, seg.data_ptr<float>(), vertex.data_ptr<float>(), ip, ie, sp,
+                                  ws.data_ptr(), n, mask.data_ptr<int64_t>(), kpt.data_ptr<float>(), cov.data_ptr<float>(),
+                                  weights.data_ptr<float>(), win.data_ptr<int32_t>(), tn.data_ptr<int32_t>(),
+                                  cur_stream(vertex)),
+       "decode_keypoint_un_pnp");
+    return {kpt, mask, cov, weights, win, tn};
+}
+
 // estimate_voting_distribution_with_mean for the whole batch
 // -> (cov [b,vn,2,2], hyp [b,vn,hn,2] | empty, counts [b,vn,hn] | empty, tn [b], weights [b,vn,3])
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> estimate_voting_distribution(
@@ -353,6 +394,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("seg"), py::arg("vertex"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"),
           py::arg("max_num"), py::arg("idxs"), py::arg("selection"), py::arg("seed"), py::arg("singular_policy"),
           py::arg("first_image") = 0);
+    m.def("decode_keypoint_un_pnp", &decode_keypoint_un_pnp,
+          "argmax(seg) + ransac_voting_layer_v3 + estimate_voting_distribution_with_mean in one pass (two-class seg)",
+          py::arg("seg"), py::arg("vertex"), py::arg("round_hyp_num"), py::arg("hyp_est"), py::arg("inlier_thresh"),
+          py::arg("min_num"), py::arg("max_num"), py::arg("idxs"), py::arg("idxs_est"), py::arg("selection"), py::arg("seed"),
+          py::arg("singular_policy"), py::arg("first_image") = 0);
     m.def("estimate_voting_distribution", &estimate_voting_distribution,
           "batched estimate_voting_distribution_with_mean", py::arg("mask"), py::arg("vertex"), py::arg("mean"),
           py::arg("hyp_total"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"), py::arg("idxs"),

@@ -19,7 +19,8 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
     const int *__restrict__ tn_arr, const float2 *__restrict__ coords,
     const float2 *__restrict__ dirs, const float2 *__restrict__ hyps,
     const int *__restrict__ counts, double *__restrict__ sums /*[B,K,nsplit,5]*/,
-    int *__restrict__ win_counts /*[B,K] or null*/, int K, int hn, int cap, float thresh, int nsplit)
+    int *__restrict__ win_counts /*[B,K] or null*/, int K, int hn, int hstride /*row length of hyps / counts (>= hn)*/,
+    int cap, float thresh, int nsplit)
 {
     __shared__ int s_cnt[4], s_idx[4];
     __shared__ double red5[20];
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
         return;
     }
     // torch.max(counts, 0): maximal count, FIRST index among ties (P:160)
-    const int *cp = counts + (size_t)bk * hn;
+    const int *cp = counts + (size_t)bk * hstride;
     int best = -1, besti = 0x7fffffff;
     for (int h = threadIdx.x; h < hn; h += kBlock) {
         int c = cp[h];
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
 
     // P:162-167: all_win_ratio (0) < count/tn  <=>  count > 0; otherwise the winner stays (0,0)
     float2 win = make_float2(0.f, 0.f);
-    if (best > 0) win = hyps[(size_t)bk * hn + besti];
+    if (best > 0) win = hyps[(size_t)bk * hstride + besti];
 
     // P:176-191: re-vote the winner (hn = 1) and accumulate the normal equations in binary64
     const float2 *dp = dirs + (size_t)bk * cap;

@@ -30,7 +30,7 @@ extern "C" {
 #define PVV_E_WORKSPACE (-2) /* workspace smaller than pvv_workspace_bytes() */
 
 /* ABI version of this header; pvv_abi_version() must return the same. */
-#define PVV_ABI_VERSION 3
+#define PVV_ABI_VERSION 4
 
 int pvv_abi_version(void);
 const char *pvv_last_error(void);
@@ -178,6 +178,31 @@ int pvv_estimate_voting_distribution(const pvv_problem *p, const void *d_mask,
                                      float *d_hyp, int32_t *d_counts,
                                      int32_t *d_tn, float *d_weights,
                                      void *stream);
+
+/* Resnet18.decode_keypoint with cfg.test.un_pnp (resnet18.py:65-72) as ONE pass:
+ *     mask   = argmax(seg, 1)
+ *     mean   = ransac_voting_layer_v3(mask, vertex, p->hn, inlier_thresh)        (resnet18.py:71)
+ *     kpt, var = estimate_voting_distribution_with_mean(mask, vertex, mean)       (resnet18.py:72, P:202-274)
+ * The two layers scan and compact the same mask, so here the mask is scanned once, the foreground compacted once,
+ * and ONE hypothesis launch + ONE inlier-count launch cover the p->hn hypotheses of the v3 layer and the hn_est
+ * (= ceil(min_hyp_num / round_hyp_num) * round_hyp_num, 4096 by default) of the estimate; the refit reads the
+ * first p->hn counts of a row, the covariance the rest.  Results are bit-identical to pvv_decode_keypoint_v3
+ * followed by pvv_estimate_voting_distribution on the same draws.
+ * Requires p->seg_classes == 2 (PVNet's seg_dim, config.py:108-112): v3 votes with `mask != 0`, the estimate with
+ * `mask == 1` (P:125 vs P:207), which coincide only for a two-class argmax -- PVV_E_ARG otherwise (make the two
+ * calls then).  min_num / max_num of p apply to both layers, as in the reference's call (defaults of both).
+ *   d_idxs      [B,p->hn,K,2] i32 or NULL      d_idxs_est  [B,hn_est,K,2] i32 or NULL   (device RNG where NULL)
+ *   d_kpt       [B,K,2] f32 = mean             d_cov       [B,K,2,2] f32
+ *   d_weights   [B,K,3] f32 (wxx,wxy,wyy) of inv(sqrtm(cov)) or NULL (evaluators/linemod/pvnet.py:118-128)
+ * workspace: pvv_workspace_bytes_un_pnp(p, hn_est). */
+size_t pvv_workspace_bytes_un_pnp(const pvv_problem *p, int32_t hn_est);
+int pvv_decode_keypoint_un_pnp(const pvv_problem *p, int32_t hn_est, const float *d_seg,
+                               const float *d_vertex, const int32_t *d_idxs,
+                               const int32_t *d_idxs_est, const float *d_selection,
+                               void *d_workspace, size_t workspace_bytes,
+                               int64_t *d_mask_out, float *d_kpt, float *d_cov,
+                               float *d_weights, int32_t *d_win_counts, int32_t *d_tn,
+                               void *stream);
 
 /* Bench / profiling aid: re-runs ONLY the inlier-count kernel of the last
  * layer call recorded in `d_workspace` (same problem), so its duration can be

@@ -575,6 +575,51 @@ def test_decode_keypoint_fused_argmax_equals_unfused(oracle, synth, pkg, gpu, C)
         assert np.abs(_np(o["kpt_2d"]) - _np(d["kpt_2d"])).max() < 6.0
 
 
+@pytest.mark.parametrize("policy", ["reference", "zero"])
+def test_decode_keypoint_un_pnp_one_pass_equals_the_two_calls(oracle, synth, pkg, gpu, policy):
+    """resnet18.py:71-72 (v3 with 512 hypotheses, then the estimate with 4096) as ONE pass over a two-class seg: mask,
+    keypoints, covariances and PnP weights bit-identical to decode_keypoint_v3 + estimate_voting_distribution on the
+    same injected draws; keypoints and covariances within tolerance of the oracle; more than two classes are refused."""
+    from clean_pvnet_amd import ransac_voting as ext
+    from clean_pvnet_amd.decode import decode_keypoint
+    B, H, W, K, hn, hn_est = 3, 96, 128, 5, 64, 160
+    d = synth.make_batch(B=B, H=H, W=W, K=K, fg=0.08, sigma=0.05, seed=91, planar=True)
+    x = torch.empty(B, 2 + 2 * K, H, W)
+    g = torch.Generator().manual_seed(2)
+    x[:, :2] = torch.randn(B, 2, H, W, generator=g) * 0.1
+    x[:, 0] += 1.0
+    x[:, 1][d["mask"] != 0] += 4.0
+    x[2, 1] = -9.0                                                  # an image without foreground: skipped by both layers
+    x[:, 2:] = d["vertex"].permute(0, 3, 4, 1, 2).reshape(B, 2 * K, H, W)
+    x = x.to(gpu)
+    seg, ver = x[:, :2], x[:, 2:]
+    vertex = ver.permute(0, 2, 3, 1).view(B, H, W, K, 2)
+    mask_ref = torch.argmax(seg, 1)
+    tn = [int(v) for v in (mask_ref != 0).sum((1, 2)).cpu()]
+    assert tn[2] == 0 and min(tn[:2]) > 100
+    idxs = synth.make_idxs(tn, hn, K, seed=91).to(gpu)
+    idxs_est = synth.make_idxs(tn, hn_est, K, seed=92).to(gpu)
+    pol = ext.SINGULAR_REFERENCE if policy == "reference" else ext.SINGULAR_ZERO
+    kpt2, mask2, win2, tn2 = ext.decode_keypoint_v3(seg, vertex, hn, 0.99, 5, 30000, idxs, None, 0, pol)
+    cov2, _h, _c, _t, w2 = ext.estimate_voting_distribution(mask2, vertex, kpt2, hn_est, 0.99, 5, 30000, idxs_est, None, 0, False)
+    kpt, mask, cov, w, win, tnn = ext.decode_keypoint_un_pnp(seg, vertex, hn, hn_est, 0.99, 5, 30000, idxs, idxs_est, None, 0, pol)
+    for a, b in ((mask, mask2), (kpt, kpt2), (cov, cov2), (w, w2), (win, win2), (tnn, tn2)):
+        assert torch.equal(a, b)
+    want = oracle.ransac_voting_layer_v3(_np(mask_ref), _np(vertex), hn, 0.99, idxs=_np(idxs), singular=policy)
+    np.testing.assert_allclose(_np(kpt), want, rtol=0, atol=ATOL)
+    _m, want_cov = oracle.estimate_voting_distribution_with_mean(_np(mask_ref), _np(vertex), want, hn_est, hn_est,
+                                                                 idxs=_np(idxs_est))
+    np.testing.assert_allclose(_np(cov), want_cov, rtol=1e-3, atol=1e-3)    # mean differs by <= 1e-4 px from the oracle's
+    # the dict mirror takes the one-pass route for a two-class seg (512 + 4096 hypotheses, device RNG)
+    o = decode_keypoint({"seg": seg, "vertex": ver}, un_pnp=True, weights=True)
+    assert set(o) == {"seg", "vertex", "mask", "kpt_2d", "var", "var_weights"}
+    assert torch.equal(o["mask"], mask_ref) and o["var"].shape == (B, K, 2, 2) and o["var_weights"].shape == (B, K, 3)
+    assert np.abs(_np(o["kpt_2d"][:2]) - _np(d["kpt_2d"][:2])).max() < 6.0
+    seg3 = torch.cat([seg, seg[:, :1] - 5.0], 1)
+    with pytest.raises(RuntimeError, match="seg_classes == 2"):
+        ext.decode_keypoint_un_pnp(seg3, vertex, hn, hn_est, 0.99, 5, 30000, idxs, idxs_est, None, 0, pol)
+
+
 # --------------------------------------------------------------------------------------------------
 # the guard band of the default (bf16 matrix-core prefilter) kernel, through the batched path
 # --------------------------------------------------------------------------------------------------
