@@ -43,7 +43,15 @@ def gather_results(local, batch, group=None, async_op=False):
     return (out[:batch], work) if async_op else out[:batch]
 
 
-def sharded_vote(vote_fn, mask_local, vertex_local, batch, *args, group=None, **kwargs):
-    """Run ``vote_fn`` (e.g. ``ransac_voting_layer_v3``) on this rank's shard and gather ``[batch,vn,2]``."""
+def sharded_vote(vote_fn, mask_local, vertex_local, batch, *args, group=None, seed=None, **kwargs):
+    """Run ``vote_fn`` (e.g. ``ransac_voting_layer_v3``) on this rank's shard and gather ``[batch,vn,2]``.
+
+    ``seed`` (the same integer on every rank) makes the result independent of the sharding: every rank then votes with
+    ``seed=seed, first_image=<index of its first image>``, and the device RNG -- keyed by (seed, global image index) --
+    draws for image i exactly what a single-GPU call on the whole batch draws.  Without it every rank draws its own key."""
+    if seed is not None:
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank(group) if world > 1 else 0
+        kwargs = dict(kwargs, seed=int(seed), first_image=shard_bounds(batch, world, rank)[0])
     local = vote_fn(mask_local, vertex_local, *args, **kwargs)
     return gather_results(local, batch, group)

@@ -12,6 +12,10 @@ Keyword-only additions (all default to reference behaviour):
              :145 / :235); None = counter-based RNG on the device
   selection  injected U(0,1) draws ``[b,h,w]`` float32 (the ``uniform_`` of :136 / :220)
   singular   "reference" | "zero" -- see ``ransac_voting_layer_v3``
+  seed, first_image   key of the device RNG (used where nothing is injected): ``seed`` defaults to a draw from torch's
+             CPU generator; the generator is keyed by ``(seed, first_image + b)``, so the shards of a batch -- one per
+             GPU, ``first_image`` = index of the shard's first image -- draw exactly what one call on the whole batch
+             draws with the same ``seed`` (``clean_pvnet_amd.dist.sharded_vote(..., seed=)`` does this)
 """
 import numpy as np
 import torch
@@ -49,22 +53,24 @@ def _chunks(b):
     return [(lo, min(b, lo + _MAX_BATCH)) for lo in range(0, b, _MAX_BATCH)]
 
 
-def _vote_v3(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, idxs, selection, policy):
+def _vote_v3(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, idxs, selection, policy, seed=None,
+             first_image=0):
     b = vertex.shape[0]
     mask = _as_mask(mask, False)
     outs = []
-    seed = _next_seed()     # one key for the whole batch; the device RNG is keyed by (seed, image index), so the
+    seed = _next_seed() if seed is None else int(seed)   # one key for the whole batch; the device RNG is keyed by (seed, image index), so the
     for lo, hi in _chunks(b):   # split below is invisible in the results
         out, _win, _tn, _ws = _ext.ransac_voting_v3(
             mask[lo:hi], vertex[lo:hi], int(round_hyp_num), float(inlier_thresh), int(min_num), int(max_num),
             None if idxs is None else idxs[lo:hi], None if selection is None else selection[lo:hi],
-            seed, policy, lo)
+            seed, policy, int(first_image) + lo)
         outs.append(out)
     return outs[0] if len(outs) == 1 else torch.cat(outs)
 
 
 def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
-                           min_num=5, max_num=30000, *, idxs=None, selection=None, singular="reference"):
+                           min_num=5, max_num=30000, *, idxs=None, selection=None, singular="reference", seed=None,
+                           first_image=0):
     '''
     :param mask:      [b,h,w]
     :param vertex:    [b,h,w,vn,2]
@@ -85,11 +91,11 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     '''
     del confidence, max_iter
     return _vote_v3(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, idxs, selection,
-                    _POLICY[singular])
+                    _POLICY[singular], seed, first_image)
 
 
 def ransac_voting_layer(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
-                        min_num=5, max_num=30000, *, idxs=None, selection=None):
+                        min_num=5, max_num=30000, *, idxs=None, selection=None, seed=None, first_image=0):
     '''
     :param mask:      [b,h,w]
     :param vertex:    [b,h,w,vn,2]
@@ -102,7 +108,7 @@ def ransac_voting_layer(mask, vertex, round_hyp_num, inlier_thresh=0.999, confid
     '''
     del confidence, max_iter
     return _vote_v3(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, idxs, selection,
-                    _POLICY["image_zero"])
+                    _POLICY["image_zero"], seed, first_image)
 
 
 def b_inv(b_mat):
@@ -121,7 +127,7 @@ def b_inv(b_mat):
 
 def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256, min_hyp_num=4096, topk=128,
                                            inlier_thresh=0.99, min_num=5, max_num=30000, output_hyp=False, *,
-                                           idxs=None, selection=None, return_weights=False):
+                                           idxs=None, selection=None, return_weights=False, seed=None, first_image=0):
     '''
     :param mask:   [b,h,w]   foreground is ``mask == 1`` (:207)
     :param vertex: [b,h,w,vn,2]
@@ -143,12 +149,12 @@ def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256
     mask = _as_mask(mask, True)
     mean_c = mean.contiguous().float()
     covs, hyps, ratios, wts = [], [], [], []
-    seed = _next_seed()
+    seed = _next_seed() if seed is None else int(seed)
     for lo, hi in _chunks(b):
         cov, hyp, counts, tn, w = _ext.estimate_voting_distribution(
             mask[lo:hi], vertex[lo:hi], mean_c[lo:hi], hn_total, float(inlier_thresh), int(min_num),
             int(max_num), None if idxs is None else idxs[lo:hi],
-            None if selection is None else selection[lo:hi], seed, bool(output_hyp), lo)
+            None if selection is None else selection[lo:hi], seed, bool(output_hyp), int(first_image) + lo)
         covs.append(cov)
         wts.append(w)
         if output_hyp:

@@ -43,6 +43,15 @@ def _worker(rank, world, port, batch, q):
 
         if d is not None:
             out = pdist.sharded_vote(vote, d["mask"], d["vertex"], batch, cfg["hn"])
+            # seed= : every rank votes with the common key and the index of ITS first image (device-RNG results are
+            # then independent of the sharding)
+            seen = {}
+
+            def vote_kw(mask, vertex, hn, **kw):
+                seen.update(kw)
+                return vote(mask, vertex, hn)
+            out_s = pdist.sharded_vote(vote_kw, d["mask"], d["vertex"], batch, cfg["hn"], seed=777)
+            assert seen == {"seed": 777, "first_image": lo} and torch.equal(out_s, out)
         else:
             out = pdist.gather_results(torch.zeros(0, cfg["K"], 2), batch)
         cov_local = torch.arange((hi - lo) * cfg["K"] * 4, dtype=torch.float32).view(hi - lo, cfg["K"], 2, 2) + 1000 * rank

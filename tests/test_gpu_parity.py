@@ -888,6 +888,23 @@ def test_device_rng_is_keyed_by_global_image_index(synth, pkg, gpu):
         assert not torch.equal(other[1], parts[1][1])                     # first_image = 0 there: different draws
 
 
+def test_python_layers_are_invariant_to_sharding_with_a_common_seed(synth, pkg, gpu):
+    """seed= / first_image= of the drop-in layers: voting on the shards of a batch (what N GPUs do) with the common seed
+    gives, image by image, exactly the result of one call on the whole batch -- device RNG, nothing injected."""
+    from clean_pvnet_amd.ransac_voting_gpu import estimate_voting_distribution_with_mean, ransac_voting_layer_v3
+    d = synth.make_batch(B=5, H=96, W=128, K=3, fg=0.12, sigma=0.05, seed=88, device=gpu)
+    mask, vertex = d["mask"], d["vertex"]
+    whole = ransac_voting_layer_v3(mask, vertex, 64, inlier_thresh=0.99, seed=2024)
+    parts = [ransac_voting_layer_v3(mask[lo:hi], vertex[lo:hi], 64, inlier_thresh=0.99, seed=2024, first_image=lo)
+             for lo, hi in ((0, 3), (3, 5))]
+    assert torch.equal(whole, torch.cat(parts))
+    assert not torch.equal(whole, ransac_voting_layer_v3(mask, vertex, 64, inlier_thresh=0.99, seed=2025))
+    _m, cov = estimate_voting_distribution_with_mean(mask, vertex, whole, 32, 64, seed=7)
+    covs = [estimate_voting_distribution_with_mean(mask[lo:hi], vertex[lo:hi], whole[lo:hi], 32, 64, seed=7, first_image=lo)[1]
+            for lo, hi in ((0, 2), (2, 5))]
+    assert torch.equal(cov, torch.cat(covs))
+
+
 def test_full_hd_frame_with_subsampling(oracle, synth, pkg, gpu):
     """1080x1920 (1013 compaction tiles, coordinates up to 1919), ~2 % foreground = 41 k pixels > max_num -> subsampled to
     ~30 k with injected draws; K = 9, 512 hypotheses; counts bit-exact, means within 1e-4."""
