@@ -1,4 +1,4 @@
-// compaction.hpp -- stage 1: mask scan, subsample, ordered compaction.
+// compaction.hpp -- stages 1 and 2: mask scan, subsample, ordered compaction, hypothesis generation.
 // Part of the single translation unit pvnet_vote.hip (included inside its anonymous namespace); see that file
 // for the numerical contract and the reference citations (K = ransac_voting_kernel.cu, P = ransac_voting_gpu.py).
 #pragma once
@@ -6,6 +6,14 @@
 // ---------------------------------------------------------------------------------------------
 // Stage 1: foreground compaction (replaces sum / nonzero / masked_select / uniform_ of
 // P:125-144 and P:207-229), order = row-major order of torch.nonzero.
+//
+// The image is cut into tiles of kTile = 2048 consecutive pixels.  k_tile_scan -- the ONLY pass over the mask --
+// leaves per tile (i) one packed word: foreground pixels | weight sum << 12 (foreground_num of P:126 sums byte
+// VALUES), (ii) the tile's foreground pixels as an ordered list of 16-bit offsets.  Everything downstream works from
+// those lists: the subsample (k_tile_subsample, or fused into k_compact_hyp) filters them, the compaction blocks of
+// k_compact_hyp gather the vertex field through them, and its hypothesis blocks pick the t-th foreground pixel of an
+// image by a search in the tile prefix + ONE list read -- so hypotheses need not wait for the compaction and the
+// separate hypothesis launch of round 1 is gone.
 // ---------------------------------------------------------------------------------------------
 struct MaskArgs {
     const void *mask;
@@ -19,13 +27,15 @@ struct MaskArgs {
     uint64_t seed;
     int b0;                  // first_image: RNG key offset of image 0
     int *tn_user;            // the caller's tn[B] (or nullptr): written beside the workspace copy, no D2D copy later
-    int fuse_sub;            // 1: k_compact applies the subsampling itself (no k_tile_subsample launch), see there
+    int fuse_sub;            // 1: k_compact_hyp applies the subsampling itself (no k_tile_subsample launch), see there
     // fused argmax (decode_keypoint): when seg != nullptr the mask value is argmax_c seg[b,c,y,x]
     const float *seg;
     long long *mask_out;     // [B,H,W] int64 or nullptr
     int64_t gb, gc, gh, gw;  // element strides of seg
     int C;
 };
+
+constexpr uint32_t kTileNzMask = 0xfffu;   // tiles[] word: foreground pixels (0..2048) | weight sum (<= 2048*255) << 12
 
 template <int ES>
 __device__ __forceinline__ uint64_t load_elem(const void *base, int64_t off)
@@ -36,8 +46,6 @@ __device__ __forceinline__ uint64_t load_elem(const void *base, int64_t off)
     return ((const uint64_t *)base)[off];
 }
 
-// weight of pixel p of image b: 0 = background; v3: low byte (P:125-126 sums the bytes),
-// estimate: 1 (P:207-208).
 // torch.argmax over the class axis: first maximal index, a NaN beats everything (and the first NaN wins)
 __device__ __forceinline__ int argmax_class(const MaskArgs &a, int b, int p)
 {
@@ -53,6 +61,7 @@ __device__ __forceinline__ int argmax_class(const MaskArgs &a, int b, int p)
     return idx;
 }
 
+// weight of pixel p of image b: 0 = background; v3: low byte (P:125-126 sums the bytes), estimate: 1 (P:207-208).
 template <int ES>
 __device__ __forceinline__ int mask_weight(const MaskArgs &a, int b, int p)
 {
@@ -81,73 +90,141 @@ __device__ __forceinline__ float selection_draw(const MaskArgs &a, int b, int p)
     return (float)(rng_u32(a.seed, 0u, (uint32_t)(a.b0 + b), (uint32_t)p) >> 8) * 0x1p-24f;
 }
 
-// Pass 1 -- the ONLY pass that reads the mask: per tile of 2048 pixels the foreground count, the weight sum
-// (foreground_num of P:126 sums byte VALUES) and a 2048-bit foreground map (one wave64 ballot per 64 pixels,
-// word s*4+w = step s, wave w).  Later passes work from the bit map.
-template <int ES>
-__global__ __launch_bounds__(kBlock) void k_tile_count(MaskArgs a, int *__restrict__ tile_nz,
-                                                       int *__restrict__ tile_sum,
-                                                       unsigned long long *__restrict__ bits)
+// Exclusive scan of the 32 (step, wave) segment counts of a tile by wave 0; seg[32] = the tile's total.
+// Call with all threads; contains the barriers.
+__device__ __forceinline__ void scan_segments(int *seg)
 {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int c = lane < kTileSteps * 4 ? seg[lane] : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int n = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += n;
+        }
+        if (lane < kTileSteps * 4) seg[lane] = inc - c;
+        if (lane == kTileSteps * 4 - 1) seg[kTileSteps * 4] = inc;
+    }
+    __syncthreads();
+}
+
+// Pass 1 -- the ONLY pass that reads the mask.
+template <int ES>
+__global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__restrict__ tiles,
+                                                      unsigned short *__restrict__ tile_list)
+{
+    __shared__ int seg[kTileSteps * 4 + 1];
     __shared__ int red[4];
     const int t = blockIdx.x, b = blockIdx.y;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    unsigned long long *wb = bits + ((size_t)b * a.T + t) * (kTileSteps * 4);
-    int nz = 0, sum = 0;
+    unsigned long long m[kTileSteps];
+    int sum = 0;
 #pragma unroll
     for (int s = 0; s < kTileSteps; ++s) {
-        int p = t * kTile + s * kBlock + threadIdx.x;
+        const int p = t * kTile + s * kBlock + threadIdx.x;
         int w = 0;
         if (p < a.HW) w = mask_weight<ES>(a, b, p);
-        unsigned long long m = __ballot(w != 0);
-        if (lane == 0) wb[s * 4 + wave] = m;
-        nz += (w != 0);
+        m[s] = __ballot(w != 0);
+        if (lane == 0) seg[s * 4 + wave] = __popcll(m[s]);
         sum += w;
     }
-    nz = block_sum(nz, red);
-    sum = block_sum(sum, red);
-    if (threadIdx.x == 0) {
-        tile_nz[b * a.T + t] = nz;
-        tile_sum[b * a.T + t] = sum;
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    scan_segments(seg);
+    if (threadIdx.x == 0)
+        tiles[b * a.T + t] = (uint32_t)seg[kTileSteps * 4] | ((uint32_t)(red[0] + red[1] + red[2] + red[3]) << 12);
+    unsigned short *list = tile_list + ((size_t)b * a.T + t) * kTile;
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s)
+        if ((m[s] >> lane) & 1ull)
+            list[seg[s * 4 + wave] + __popcll(m[s] & ((1ull << lane) - 1ull))] = (unsigned short)(s * kBlock + threadIdx.x);
+}
+
+// foreground_num of P:126 / P:208 (sum of the weights) and the number of foreground pixels of image b.
+struct ImageTotals { long long fg; int total; int before; };
+
+// One pass over the image's tile table and ONE block reduction for all three sums: foreground_num, the rows of the
+// tiles before tile t, and the image's row count.  redl: 4 long long, red: 8 int.
+__device__ __forceinline__ ImageTotals image_totals(const uint32_t *__restrict__ tiles, int b, int T, int t,
+                                                    long long *redl, int *red)
+{
+    long long fgs = 0;
+    int before = 0, total = 0;
+    for (int i = threadIdx.x; i < T; i += kBlock) {
+        const uint32_t w = tiles[b * T + i];
+        fgs += w >> 12;
+        const int c = (int)(w & kTileNzMask);
+        total += c;
+        if (i < t) before += c;
     }
+    fgs = wave_sum(fgs);
+    before = wave_sum(before);
+    total = wave_sum(total);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane_id() == 0) { redl[wave] = fgs; red[wave] = before; red[4 + wave] = total; }
+    __syncthreads();
+    ImageTotals r;
+    r.fg = redl[0] + redl[1] + redl[2] + redl[3];
+    r.before = red[0] + red[1] + red[2] + red[3];
+    r.total = red[4] + red[5] + red[6] + red[7];
+    return r;
 }
 
-// foreground_num of P:126 / P:208 from the per-tile partial sums.
-__device__ __forceinline__ long long image_fg(const int *__restrict__ tile_sum, int b, int T,
-                                              long long *red)
+// Filter one tile's list by the subsample draw (keep iff U < prob), order kept: survivors land in out[] (LDS or
+// global, may alias nothing), their number is returned to every thread.  seg: kTileSteps*4+1 ints of LDS.
+__device__ __forceinline__ int filter_tile_list(const MaskArgs &a, int b, int t, int nz, float prob,
+                                                const unsigned short *__restrict__ list, unsigned short *out, int *seg)
 {
-    long long s = 0;
-    for (int i = threadIdx.x; i < T; i += kBlock) s += tile_sum[b * T + i];
-    return block_sum(s, red);
-}
-
-// P:135-138 / P:219-223: when foreground_num > max_num every foreground pixel survives with
-// probability max_num/foreground_num (binary32 quotient).  Clears the dropped pixels in the bit map and
-// recounts the tile.  Images that are not subsampled exit at once.
-__global__ __launch_bounds__(kBlock) void k_tile_subsample(MaskArgs a, int *__restrict__ tile_nz,
-                                                           const int *__restrict__ tile_sum,
-                                                           unsigned long long *__restrict__ bits)
-{
-    __shared__ long long redl[4];
-    __shared__ int red[4];
-    const int t = blockIdx.x, b = blockIdx.y;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    long long fg = image_fg(tile_sum, b, a.T, redl);
-    if (fg <= (long long)a.max_num) return;
-    const float prob = (float)a.max_num / (float)fg;
-    unsigned long long *wb = bits + ((size_t)b * a.T + t) * (kTileSteps * 4);
-    int nz = 0;
+    unsigned long long m[kTileSteps];
+    unsigned short off[kTileSteps];
 #pragma unroll
     for (int s = 0; s < kTileSteps; ++s) {
-        int p = t * kTile + s * kBlock + threadIdx.x;
-        bool f = (wb[s * 4 + wave] >> lane) & 1ull;
-        if (f) f = selection_draw(a, b, p) < prob;
-        unsigned long long m = __ballot(f);
-        if (lane == 0) wb[s * 4 + wave] = m;
-        nz += f ? 1 : 0;
+        const int e = s * kBlock + threadIdx.x;
+        bool f = false;
+        off[s] = 0;
+        if (e < nz) {
+            off[s] = list[e];
+            f = selection_draw(a, b, t * kTile + off[s]) < prob;
+        }
+        m[s] = __ballot(f);
+        if (lane == 0) seg[s * 4 + wave] = __popcll(m[s]);
     }
-    nz = block_sum(nz, red);
-    if (threadIdx.x == 0) tile_nz[b * a.T + t] = nz;
+    scan_segments(seg);
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s)
+        if ((m[s] >> lane) & 1ull) out[seg[s * 4 + wave] + __popcll(m[s] & ((1ull << lane) - 1ull))] = off[s];
+    return seg[kTileSteps * 4];
+}
+
+// P:135-138 / P:219-223 as its own pass (large images, or max_num so small that nearly every image is subsampled):
+// when foreground_num > max_num every foreground pixel survives with probability max_num/foreground_num (binary32
+// quotient).  Rewrites the tile's list in place and its count; tiles without foreground and images that are not
+// subsampled exit at once.
+__global__ __launch_bounds__(kBlock) void k_tile_subsample(MaskArgs a, uint32_t *__restrict__ tiles,
+                                                           unsigned short *__restrict__ tile_list)
+{
+    __shared__ long long redl[4];
+    __shared__ int red[8];
+    __shared__ int seg[kTileSteps * 4 + 1];
+    __shared__ unsigned short keep[kTile];
+    const int t = blockIdx.x, b = blockIdx.y;
+    const uint32_t w = tiles[b * a.T + t];
+    const int nz = (int)(w & kTileNzMask);
+    if (nz == 0) return;
+    const ImageTotals tot = image_totals(tiles, b, a.T, t, redl, red);
+    if (tot.fg <= (long long)a.max_num) return;
+    const float prob = (float)a.max_num / (float)tot.fg;
+    unsigned short *list = tile_list + ((size_t)b * a.T + t) * kTile;
+    const int n = filter_tile_list(a, b, t, nz, prob, list, keep, seg);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kBlock) list[i] = keep[i];
+    // In place: the other blocks of the image may still be reading the table, but they only use the weight sums
+    // (foreground_num), which this update keeps; the pixel COUNT is read by later kernels only.
+    if (threadIdx.x == 0) tiles[b * a.T + t] = (uint32_t)n | (w & ~kTileNzMask);
 }
 
 struct VertexArgs {
@@ -155,153 +232,218 @@ struct VertexArgs {
     int64_t sb, sh, sw, sk, sc;
     int K;
     int vec2;  // sc == 1 and every other stride even: (x,y) is one aligned 8-byte load
-    double kappa;  // thresh / sqrt(1 - thresh^2) for the fast-path records, 0 = no records
 };
 
-// Per (image, keypoint, compacted pixel) record of the fast inlier test, 32 bytes = one
-// s_load_dwordx8 in the count kernel:
-//   lo = (cx, cy, nhx, nhy)   nh = n / |n|  (binary64 quotient rounded once)
-//   hi = (Bx, By, nx, ny)     B  = kappa * perp(nh); (nx,ny) raw, for the exact fallback
-// A pixel the exact test can never accept (K:121: norm1 < 1e-6, or a non-finite norm1) gets
-// cx = +inf, nh = (1,0), B = (1,0): then a = b' = -inf, t = a - |b'| = -inf (never an inlier) and the
-// ambiguity measure is +inf (never flagged).
-struct __attribute__((aligned(32))) PixelRec {
-    float4 lo, hi;
-};
-
-__device__ __forceinline__ PixelRec make_record(float cx, float cy, float nx, float ny, double kappa)
+__device__ __forceinline__ float2 load_vertex(const VertexArgs &v, int b, int y, int x, int vi)
 {
-    PixelRec r;
-    float norm1 = sqrtf(nx * nx + ny * ny);           // the exact path's own norm1 (K:116)
-    bool ok = !lt_1e6(norm1) && norm1 < INFINITY && norm1 == norm1;
-    if (ok) {
-        double N1 = sqrt((double)nx * (double)nx + (double)ny * (double)ny);
-        double ux = (double)nx / N1, uy = (double)ny / N1;
-        r.lo = make_float4(cx, cy, (float)ux, (float)uy);
-        r.hi = make_float4((float)(-kappa * uy), (float)(kappa * ux), nx, ny);
-    } else {
-        r.lo = make_float4(INFINITY, 0.f, 1.f, 0.f);
-        r.hi = make_float4(1.f, 0.f, nx, ny);
-    }
-    return r;
+    const float *src = v.vertex + (int64_t)b * v.sb + (int64_t)y * v.sh + (int64_t)x * v.sw + (int64_t)vi * v.sk;
+    if (v.vec2) return *(const float2 *)src;
+    return make_float2(src[0], src[v.sc]);
 }
 
-// Ordered scatter: pixel -> row r of the image's compacted list; writes coords[b][r] = (x,y)
-// (P:140-141) and dirs[b][vi][r] = vertex[b,y,x,vi,:] (P:142-143, stored planar per keypoint so
-// that the count kernel's loads are unit-stride).
-__global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
-                                                    const int *__restrict__ tile_nz,
-                                                    const int *__restrict__ tile_sum,
-                                                    const unsigned long long *__restrict__ bits,
-                                                    int *__restrict__ tn_out,
-                                                    float2 *__restrict__ coords,
-                                                    float2 *__restrict__ dirs,
-                                                    PixelRec *__restrict__ recs)
+// ---------------------------------------------------------------------------------------------
+// Stage 2: hypotheses (replaces random_ P:145/P:235 + generate_hypothesis K:11-86); zeroes the inlier counters.
+// ---------------------------------------------------------------------------------------------
+struct HypArgs {
+    const int32_t *idxs;     // [B,hn_first,K,2] or null
+    const int32_t *idxs2;    // [B,hn-hn_first,K,2] or null (the estimate's rounds of a fused un_pnp call)
+    int hn, hn_first;        // hypotheses [0,hn_first) draw from idxs / RNG stream `stream`, the rest from idxs2 / `stream2`
+    uint32_t stream, stream2;
+    float2 *hyps;            // [B,K,hn]
+    int *counts;             // [B,K,hn]
+    int32_t *draws_out;      // [B,K,hn,2] or null: the pixel (y*W+x) each index pair resolved to (tests)
+    int blocks;              // hypothesis blocks per image
+};
+
+constexpr int kHypRejectTries = 1 << 12;
+
+// Row t of the image's (not yet written) compacted list -> pixel: search the inclusive tile prefix, then one read of
+// the tile's list.
+__device__ __forceinline__ int select_pixel(const int *prefix, int T, const unsigned short *__restrict__ lists /*of image b*/, int t)
 {
+    int lo = 0, hi = T - 1;               // smallest i with prefix[i] > t
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    const int r = t - (lo ? prefix[lo - 1] : 0);
+    return lo * kTile + (int)lists[(size_t)lo * kTile + r];
+}
+
+// Ordered scatter + hypotheses, one launch, grid (T + h.blocks, B):
+//  * blocks x < T   (compaction): pixel list of tile x -> rows of the image's compacted arrays: coords[b][r] = (x,y)
+//    (P:140-141) and dirs[b][vi][r] = vertex[b,y,x,vi,:] (P:142-143, planar per keypoint so that the count kernel's
+//    loads are unit-stride);
+//  * blocks x >= T  (hypotheses): 256 hypotheses each, straight from the tile lists and the vertex field.
+// Dynamic LDS: T ints (the tile prefix of the hypothesis blocks).
+__global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v, HypArgs h,
+                                                        const uint32_t *__restrict__ tiles,
+                                                        const unsigned short *__restrict__ tile_list,
+                                                        int *__restrict__ tn_out, float2 *__restrict__ coords,
+                                                        float2 *__restrict__ dirs)
+{
+    extern __shared__ int s_prefix[];
     __shared__ long long redl[4];
     __shared__ int red[8];
     __shared__ int seg[kTileSteps * 4 + 1];
     __shared__ unsigned short list[kTile];
-    const int t = blockIdx.x, b = blockIdx.y;
+    const int b = blockIdx.y;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const unsigned short *img_lists = tile_list + (size_t)b * a.T * kTile;
 
-    // background-only tile: nothing to scatter (tile 0 reports tn; with fused subsampling the last tile does)
-    if (t != 0 && !(a.fuse_sub && t == a.T - 1) && tile_nz[b * a.T + t] == 0) return;
-
-    // this tile's foreground map, requested before the reductions below so that the two latencies overlap
-    const unsigned long long *wb = bits + ((size_t)b * a.T + t) * (kTileSteps * 4);
-    unsigned long long word[kTileSteps];
+    if ((int)blockIdx.x >= a.T) {
+        // ------------------------------------------------------------------ hypothesis block
+        const int j = blockIdx.x - a.T;
+        // inclusive prefix of the tile counts in LDS (+ foreground_num), 256 tiles per round
+        long long fgs = 0;
+        int carry = 0;
+        for (int base = 0; base < a.T; base += kBlock) {
+            const int i = base + threadIdx.x;
+            const uint32_t w = i < a.T ? tiles[b * a.T + i] : 0u;
+            fgs += w >> 12;
+            int inc = (int)(w & kTileNzMask);
 #pragma unroll
-    for (int s = 0; s < kTileSteps; ++s) word[s] = wb[s * 4 + wave];   // wave-uniform
+            for (int o = 1; o < 64; o <<= 1) {
+                const int n = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += n;
+            }
+            __syncthreads();
+            if (lane == 63) red[wave] = inc;
+            __syncthreads();
+            int off = carry;
+            for (int w2 = 0; w2 < wave; ++w2) off += red[w2];
+            if (i < a.T) s_prefix[i] = inc + off;
+            carry += red[0] + red[1] + red[2] + red[3];
+        }
+        fgs = wave_sum(fgs);
+        __syncthreads();
+        if (lane == 0) redl[wave] = fgs;
+        __syncthreads();
+        const long long fg = redl[0] + redl[1] + redl[2] + redl[3];
+        const int total = carry;                                  // rows before any truncation at cap
+        int tn = total < a.cap ? total : a.cap;
+        if (fg < (long long)a.min_num) tn = 0;                    // P:129-132 / P:211-216
+        // subsampling fused into this launch (a.fuse_sub): the lists still hold EVERY foreground pixel; a pixel
+        // survives iff its draw < prob.  The index pairs then come from rejection sampling -- uniform over the
+        // survivors, which is what randint(0, tn) over the subsampled list is -- so nothing has to wait for the
+        // compaction (the host never fuses when index pairs are injected: those address the subsampled order).
+        const bool sub = a.fuse_sub && fg > (long long)a.max_num;
+        const float prob = sub ? (float)a.max_num / (float)fg : 2.f;
 
-    // one pass over the image's tile table and ONE block reduction for all three sums: foreground_num (P:126 / P:208),
-    // the rows before this tile, and the image's row count
-    long long fgs = 0;
-    int before = 0, total = 0;
-    for (int i = threadIdx.x; i < a.T; i += kBlock) {
-        fgs += tile_sum[b * a.T + i];
-        const int c = tile_nz[b * a.T + i];
-        total += c;
-        if (i < t) before += c;
+        const int gid = j * kBlock + threadIdx.x;                 // hypothesis (vi, hi) of image b
+        if (gid >= v.K * h.hn) return;
+        const int vi = gid / h.hn, hi = gid - vi * h.hn;
+        const size_t o = ((size_t)b * v.K + vi) * h.hn + hi;
+        h.counts[o] = 0;
+        if (tn <= 0) {
+            h.hyps[o] = make_float2(0.f, 0.f);
+            if (h.draws_out) { h.draws_out[2 * o] = -1; h.draws_out[2 * o + 1] = -1; }
+            return;
+        }
+        const bool first = hi < h.hn_first;
+        const int32_t *src = first ? h.idxs : h.idxs2;
+        int p0, p1;
+        if (src) {
+            const int32_t *ip = first ? h.idxs + (((size_t)b * h.hn_first + hi) * v.K + vi) * 2
+                                      : h.idxs2 + (((size_t)b * (h.hn - h.hn_first) + (hi - h.hn_first)) * v.K + vi) * 2;
+            int t0 = ip[0], t1 = ip[1];
+            // the reference reads out of bounds here; clamp instead of faulting
+            t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);
+            t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
+            p0 = select_pixel(s_prefix, a.T, img_lists, t0);
+            p1 = select_pixel(s_prefix, a.T, img_lists, t1);
+        } else {
+            const uint32_t stream = first ? h.stream : h.stream2;
+            const uint32_t c = (uint32_t)((first ? hi : hi - h.hn_first) * v.K + vi) * 2u;
+            const uint32_t img = (uint32_t)(a.b0 + b);
+            if (!sub) {
+                p0 = select_pixel(s_prefix, a.T, img_lists, (int)(rng_u32(a.seed, stream, img, c) % (uint32_t)tn));
+                p1 = select_pixel(s_prefix, a.T, img_lists, (int)(rng_u32(a.seed, stream, img, c + 1u) % (uint32_t)tn));
+            } else {
+                p0 = p1 = -1;
+                for (int tr = 0; tr < kHypRejectTries && (p0 < 0 || p1 < 0); ++tr) {
+                    // try tr of draw c: key (stream + 16, image, c + tr * 2^24)  -- hn * K * 2 < 2^24 (validate())
+                    if (p0 < 0) {
+                        const int p = select_pixel(s_prefix, a.T, img_lists,
+                                                   (int)(rng_u32(a.seed, stream + 16u, img, c + ((uint32_t)tr << 24)) % (uint32_t)total));
+                        if (selection_draw(a, b, p) < prob) p0 = p;
+                    }
+                    if (p1 < 0) {
+                        const int p = select_pixel(s_prefix, a.T, img_lists,
+                                                   (int)(rng_u32(a.seed, stream + 16u, img, c + 1u + ((uint32_t)tr << 24)) % (uint32_t)total));
+                        if (selection_draw(a, b, p) < prob) p1 = p;
+                    }
+                }
+                if (p0 < 0 || p1 < 0) {                            // no survivor found (prob ~ 0): degenerate pair
+                    h.hyps[o] = make_float2(0.f, 0.f);
+                    if (h.draws_out) { h.draws_out[2 * o] = p0; h.draws_out[2 * o + 1] = p1; }
+                    return;
+                }
+            }
+        }
+        const int y0 = p0 / a.W, x0 = p0 - y0 * a.W, y1 = p1 / a.W, x1 = p1 - y1 * a.W;
+        const float2 d0 = load_vertex(v, b, y0, x0, vi), d1 = load_vertex(v, b, y1, x1, vi);
+        h.hyps[o] = hypothesis_exact(d0.x, d0.y, (float)x0, (float)y0, d1.x, d1.y, (float)x1, (float)y1);
+        if (h.draws_out) { h.draws_out[2 * o] = p0; h.draws_out[2 * o + 1] = p1; }
+        return;
     }
-    fgs = wave_sum(fgs);
-    before = wave_sum(before);
-    total = wave_sum(total);
-    if (lane == 0) { redl[wave] = fgs; red[wave] = before; red[4 + wave] = total; }
-    __syncthreads();
-    const long long fg = redl[0] + redl[1] + redl[2] + redl[3];
-    before = red[0] + red[1] + red[2] + red[3];
-    total = red[4] + red[5] + red[6] + red[7];
-    if (fg < (long long)a.min_num) {  // P:129-132 / P:211-216: image skipped
+
+    // ---------------------------------------------------------------------- compaction block of tile t
+    const int t = blockIdx.x;
+    const int nz = (int)(tiles[b * a.T + t] & kTileNzMask);
+    // background-only tile: nothing to scatter (tile 0 reports tn; with fused subsampling the last tile does)
+    if (t != 0 && !(a.fuse_sub && t == a.T - 1) && nz == 0) return;
+    const unsigned short *my_list = img_lists + (size_t)t * kTile;
+    // this tile's list, requested before the reductions below so that the two latencies overlap
+    unsigned short mine[kTileSteps];
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s) {
+        const int e = s * kBlock + threadIdx.x;
+        mine[s] = e < nz ? my_list[e] : (unsigned short)0;
+    }
+    const ImageTotals tot = image_totals(tiles, b, a.T, t, redl, red);
+    if (tot.fg < (long long)a.min_num) {  // P:129-132 / P:211-216: image skipped
         if (t == 0 && threadIdx.x == 0) {
             tn_out[b] = 0;
             if (a.tn_user) a.tn_user[b] = 0;
         }
         return;
     }
-    // P:135-138 / P:219-223 fused (images of <= kFuseSubTiles tiles; larger ones go through k_tile_subsample first):
-    // when foreground_num > max_num every foreground pixel survives with probability max_num/foreground_num.  The
-    // draws are keyed by (image, pixel), so this block redoes them for its own tile AND for the tiles before it -- it
-    // needs their survivor counts for its row offset.  Rare and bounded (<= kFuseSubTiles tiles), and it saves a launch
-    // on every call; the last tile's block reports tn.
-    const bool sub = a.fuse_sub && fg > (long long)a.max_num;
+    int before = tot.before, tile_n = nz;
+    // P:135-138 / P:219-223 fused (a.fuse_sub; otherwise k_tile_subsample ran first and the lists are final): the draws
+    // are keyed by (image, pixel), so this block redoes them for the pixels of the tiles before it -- it needs their
+    // survivor count for its row offset -- and filters its own list.  Only for images with foreground_num > max_num,
+    // and it saves a launch on every call; the last tile's block reports tn.
+    const bool sub = a.fuse_sub && tot.fg > (long long)a.max_num;
     if (sub) {
-        const float prob = (float)a.max_num / (float)fg;
+        const float prob = (float)a.max_num / (float)tot.fg;
         int cnt = 0;
         for (int i = 0; i < t; ++i) {
-            if (tile_nz[b * a.T + i] == 0) continue;                       // block-uniform
-            const unsigned long long *wi = bits + ((size_t)b * a.T + i) * (kTileSteps * 4);
-#pragma unroll
-            for (int s = 0; s < kTileSteps; ++s) {
-                const bool f = (wi[s * 4 + wave] >> lane) & 1ull;
-                if (f) cnt += selection_draw(a, b, i * kTile + s * kBlock + threadIdx.x) < prob ? 1 : 0;
-            }
+            const int ni = (int)(tiles[b * a.T + i] & kTileNzMask);                 // block-uniform
+            const unsigned short *li = img_lists + (size_t)i * kTile;
+            for (int e = threadIdx.x; e < ni; e += kBlock)
+                cnt += selection_draw(a, b, i * kTile + li[e]) < prob ? 1 : 0;
         }
-        __syncthreads();                                                   // red[] was read above
         before = block_sum(cnt, red);
+        __syncthreads();
+        tile_n = filter_tile_list(a, b, t, nz, prob, my_list, list, seg);
+        __syncthreads();
+        if (t == a.T - 1 && threadIdx.x == 0) {                                    // the last tile knows the subsampled total
+            const int all = before + tile_n;
+            tn_out[b] = all < a.cap ? all : a.cap;
+            if (a.tn_user) a.tn_user[b] = tn_out[b];
+        }
+    } else {
+        if (t == 0 && threadIdx.x == 0) {
+            tn_out[b] = tot.total < a.cap ? tot.total : a.cap;
+            if (a.tn_user) a.tn_user[b] = tn_out[b];
+        }
 #pragma unroll
         for (int s = 0; s < kTileSteps; ++s) {
-            bool f = (word[s] >> lane) & 1ull;
-            if (f) f = selection_draw(a, b, t * kTile + s * kBlock + threadIdx.x) < prob;
-            word[s] = __ballot(f);
+            const int e = s * kBlock + threadIdx.x;
+            if (e < nz) list[e] = mine[s];
         }
-    } else if (t == 0 && threadIdx.x == 0) {
-        tn_out[b] = total < a.cap ? total : a.cap;
-        if (a.tn_user) a.tn_user[b] = tn_out[b];
-    }
-
-#pragma unroll
-    for (int s = 0; s < kTileSteps; ++s)
-        if (lane == 0) seg[s * 4 + wave] = __popcll(word[s]);
-    __syncthreads();
-    if (threadIdx.x < 64) {  // wave 0: exclusive scan of the 32 (step,wave) segment counts
-        int c = threadIdx.x < kTileSteps * 4 ? seg[threadIdx.x] : 0;
-        int inc = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int n = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += n;
-        }
-        if (threadIdx.x < kTileSteps * 4) seg[threadIdx.x] = inc - c;
-        if (threadIdx.x == kTileSteps * 4 - 1) seg[kTileSteps * 4] = inc;   // foreground pixels of the tile (after subsampling)
-    }
-    __syncthreads();
-
-    // foreground pixels of the tile -> LDS list (in rank order), so that the K-fold gather below is spread over
-    // all 256 threads instead of looping inside the few lanes that own a foreground pixel
-#pragma unroll
-    for (int s = 0; s < kTileSteps; ++s) {
-        const unsigned long long m = word[s];
-        if (!((m >> lane) & 1ull)) continue;
-        const int lr = seg[s * 4 + wave] + __popcll(m & ((1ull << lane) - 1ull));   // rank within the tile
-        list[lr] = (unsigned short)(s * kBlock + threadIdx.x);
-    }
-    __syncthreads();
-    const int tile_n = seg[kTileSteps * 4];
-    if (sub && t == a.T - 1 && threadIdx.x == 0) {                       // the last tile knows the subsampled total
-        const int all = before + tile_n;
-        tn_out[b] = all < a.cap ? all : a.cap;
-        if (a.tn_user) a.tn_user[b] = tn_out[b];
+        __syncthreads();
     }
     const int room = a.cap - before;                                     // rows left in the image's list
     const int n = tile_n < room ? tile_n : (room > 0 ? room : 0);
@@ -317,35 +459,21 @@ __global__ __launch_bounds__(kBlock) void k_compact(MaskArgs a, VertexArgs v,
     for (int i0 = threadIdx.x; i0 < total_g; i0 += kGather * kBlock) {
         float2 d[kGather];
         size_t row[kGather];
-        int xs[kGather], ys[kGather];
 #pragma unroll
         for (int u = 0; u < kGather; ++u) {
             const int i = i0 + u * kBlock;
             d[u] = make_float2(0.f, 0.f);
             row[u] = 0;
-            xs[u] = ys[u] = 0;
             if (i < total_g) {
                 const int vi = i / n, li = i - vi * n;                   // consecutive threads -> consecutive rows
                 const int p = t * kTile + list[li];
                 const int y = p / a.W;
-                const int x = p - y * a.W;
-                const float *src = v.vertex + (int64_t)b * v.sb + (int64_t)y * v.sh + (int64_t)x * v.sw + (int64_t)vi * v.sk;
-                if (v.vec2) {
-                    d[u] = *(const float2 *)src;
-                } else {
-                    d[u].x = src[0];
-                    d[u].y = src[v.sc];
-                }
+                d[u] = load_vertex(v, b, y, p - y * a.W, vi);
                 row[u] = ((size_t)b * v.K + vi) * a.cap + before + li;
-                xs[u] = x; ys[u] = y;
             }
         }
 #pragma unroll
-        for (int u = 0; u < kGather; ++u) {
-            if (i0 + u * kBlock < total_g) {
-                dirs[row[u]] = d[u];
-                if (v.kappa != 0.0) recs[row[u]] = make_record((float)xs[u], (float)ys[u], d[u].x, d[u].y, v.kappa);
-            }
-        }
+        for (int u = 0; u < kGather; ++u)
+            if (i0 + u * kBlock < total_g) dirs[row[u]] = d[u];
     }
 }

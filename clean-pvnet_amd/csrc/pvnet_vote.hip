@@ -30,11 +30,12 @@ namespace {
 constexpr int kBlock = 256;          // 4 wavefronts
 constexpr int kTileSteps = 8;
 constexpr int kTile = kBlock * kTileSteps;  // pixels per compaction tile
-// Images of up to this many 2048-pixel tiles (480x640 = 150) subsample inside k_compact: one launch less on every call
-// (-3 % at B = 64, -5 % at B = 1 on MI355X).  When subsampling does trigger, every block redoes the draws of the tiles
-// before it, a cost that grows with the square of the tile count: at 190 tiles (540x720, BASELINE config 5, whose
+// Images of up to this many 2048-pixel tiles (480x640 = 150) subsample inside k_compact_hyp: one launch less on every
+// call (-3 % at B = 64, -5 % at B = 1 on MI355X).  When subsampling does trigger, every block redoes the draws of the
+// tiles before it, a cost that grows with the square of the tile count: at 190 tiles (540x720, BASELINE config 5, whose
 // 31 k foreground pixels ARE subsampled) it already outweighs the launch (+2 %), so larger images keep k_tile_subsample.
 constexpr int kFuseSubTiles = 160;
+constexpr int kMaxTiles = 16000;     // tile prefix of an image in (dynamic) LDS: 64 KB => images up to ~32 Mpixel
 constexpr int kPixPerWave = 64;      // pixels one wave walks per work item of the exact count kernel
 
 thread_local char g_err[512] = "";
@@ -57,9 +58,7 @@ int check_launch(const char *what)
 
 #include "vote_common.hpp"
 #include "compaction.hpp"
-#include "hypothesis.hpp"
 #include "count_exact.hpp"
-#include "count_fast.hpp"
 #include "count_bf16.hpp"
 #include "refit.hpp"
 #include "covariance.hpp"
@@ -72,10 +71,8 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
     int T;
-    size_t tile_nz, tile_sum, bits, tn, coords, dirs, recs, hyps, counts, sums, total;
+    size_t tiles, tile_list, tn, coords, dirs, hyps, counts, sums, total;
 };
-
-bool needs_pixel_records(const pvv_problem *p);   // only k_count_fast reads the PixelRec array
 
 Layout make_layout(const pvv_problem *p)
 {
@@ -84,13 +81,11 @@ Layout make_layout(const pvv_problem *p)
     L.T = (int)((HW + kTile - 1) / kTile);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
-    L.tile_nz = take(sizeof(int) * (size_t)p->B * L.T);
-    L.tile_sum = take(sizeof(int) * (size_t)p->B * L.T);
-    L.bits = take(sizeof(unsigned long long) * (size_t)p->B * L.T * kTileSteps * 4);
+    L.tiles = take(sizeof(uint32_t) * (size_t)p->B * L.T);
+    L.tile_list = take(sizeof(unsigned short) * (size_t)p->B * L.T * kTile);
     L.tn = take(sizeof(int) * (size_t)p->B);
     L.coords = take(sizeof(float2) * (size_t)p->B * p->cap);
     L.dirs = take(sizeof(float2) * (size_t)p->B * p->K * p->cap);
-    L.recs = take(needs_pixel_records(p) ? sizeof(PixelRec) * (size_t)p->B * p->K * p->cap : 0);
     L.hyps = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
     L.counts = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
     L.sums = take(sizeof(double) * (size_t)p->B * p->K * kRefitSplitMax * 5);
@@ -104,7 +99,9 @@ int validate(const pvv_problem *p)
     if (p->B <= 0 || p->H <= 0 || p->W <= 0 || p->K <= 0 || p->hn <= 0)
         return fail(PVV_E_ARG, "B, H, W, K, hn must be positive");
     if (p->B > kMaxBatchLds) return fail(PVV_E_ARG, "B > 1024: split the batch");
-    if ((long long)p->H * p->W >= (1ll << 31)) return fail(PVV_E_ARG, "H*W must be < 2^31");
+    if (((long long)p->H * p->W + kTile - 1) / kTile > kMaxTiles) return fail(PVV_E_ARG, "H*W too large (more than 16000 tiles of 2048 pixels)");
+    if ((long long)p->K * p->hn >= (1ll << 23)) return fail(PVV_E_ARG, "K*hn must be < 2^23");
+    if (p->count_kernel != PVV_COUNT_AUTO && p->count_kernel != PVV_COUNT_EXACT) return fail(PVV_E_ARG, "unknown count_kernel");
     if (p->mask_elem_size != 1 && p->mask_elem_size != 2 && p->mask_elem_size != 4 &&
         p->mask_elem_size != 8)
         return fail(PVV_E_ARG, "mask_elem_size must be 1, 2, 4 or 8");
@@ -119,15 +116,17 @@ int validate(const pvv_problem *p)
 
 int num_cus()
 {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
+    // per device: one process may drive several GPUs (the bench and RCCL use one process per GPU, tests need not)
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        int n = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        cus[dev] = n > 0 ? n : 256;
     }
-    return cus;
+    return cus[dev];
 }
 
 int launch_count(const CountArgs &a, hipStream_t st)
@@ -144,35 +143,13 @@ int launch_count(const CountArgs &a, hipStream_t st)
     return check_launch("k_count_inliers");
 }
 
-// The fast test needs 0 < T < 1 with a sane kappa; outside [0.5, 0.99995] (and when PVV_COUNT_KERNEL=exact
-// is set, for A/B runs) the exact kernel is used.
-// PVV_COUNT_KERNEL = exact | fast | bf16 selects the inlier-count kernel (A/B runs; the tests exercise all three).
-int count_kernel_choice()
-{
-    static int choice = -1;   // 0 exact (sqrt/divide), 1 fast (packed VALU), 2 bf16 (matrix-core prefilter)
-    if (choice < 0) {
-        const char *e = getenv("PVV_COUNT_KERNEL");
-        choice = 2;
-        if (e && !strcmp(e, "exact")) choice = 0;
-        else if (e && !strcmp(e, "fast")) choice = 1;
-    }
-    return choice;
-}
-
-bool use_fast_count(float thresh)
-{
-    return count_kernel_choice() != 0 && thresh >= 0.5f && thresh <= 0.99995f;
-}
-
+// The matrix-core prefilter needs 0 < T < 1 with a sane kappa and pixel coordinates well inside the range where the
+// block extents of its guard band are exact; outside [0.5, 0.99995], for huge images, and when the caller asks for it
+// (pvv_problem.count_kernel = PVV_COUNT_EXACT: the tests' cross-check) the exact kernel counts.
 bool use_bf16_count(const pvv_problem *p)
 {
-    // block extents enter the guard band; keep pixel coordinates well inside f32/bf16-split integer range
-    return count_kernel_choice() == 2 && use_fast_count(p->inlier_thresh) && p->H <= 16384 && p->W <= 16384;
-}
-
-bool needs_pixel_records(const pvv_problem *p)
-{
-    return use_fast_count(p->inlier_thresh) && !use_bf16_count(p);
+    return p->count_kernel == PVV_COUNT_AUTO && p->inlier_thresh >= 0.5f && p->inlier_thresh <= 0.99995f &&
+           p->H <= 16384 && p->W <= 16384;
 }
 
 Bf16Consts bf16_consts(float thresh)
@@ -186,58 +163,28 @@ Bf16Consts bf16_consts(float thresh)
     fc.kappa = (float)kappa;
     // second level: d exact-path's own, nh/B computed in f32 (<= 2u / 3u relative), one fma each => 6u(1+kappa)|d|
     fc.beta2 = (float)(1.25 * (6.0 * (1.0 + kappa) + 8.0 / s2) * u / T);
-    // PVV_DEBUG_BAND_SCALE (timing experiments only; != 1 voids the exactness guarantee): scales the guard band
+#ifdef PVV_TUNING
+    // timing experiments only (tools/build_variant.sh -DPVV_TUNING); != 1 voids the exactness guarantee
     static const char *dbg = getenv("PVV_DEBUG_BAND_SCALE");
     if (dbg && *dbg) {
         const float k = (float)atof(dbg);
         fc.beta *= k; fc.eps_c *= k; fc.eps0 *= k;
     }
+#endif
     return fc;
 }
 
-double fast_kappa_value(float thresh)
+// tuning knobs exist only in experimental builds (tools/build_variant.sh -DPVV_TUNING): the shipped library reads no
+// environment variable
+int tuning_int(const char *name, int dflt)
 {
-    const double T = (double)thresh;
-    return T / std::sqrt(1.0 - T * T);
-}
-
-FastConsts fast_consts(float thresh)
-{
-    const double T = (double)thresh, s2 = 1.0 - T * T, kappa = T / std::sqrt(s2);
-    const double u = 0x1p-24;
-    FastConsts fc;
-    fc.beta = (float)(1.25 * (3.0 * (1.0 + kappa) + 8.0 / s2) * u / T);
-    fc.eps_abs = (float)(1.5e-6 * (1.0 + kappa));
-    return fc;
-}
-
-int env_int(const char *name, int dflt)
-{
+#ifdef PVV_TUNING
     const char *e = getenv(name);
     return e && *e ? atoi(e) : dflt;
-}
-
-int launch_count_fast(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st)
-{
-    // tuning knobs (defaults from sweeps on MI355X, tools/sweep_count.sh): persistent blocks per CU, the most pixels
-    // one wave walks per work item, and how many work items per CU a small batch is still split into
-    static const int per_cu = env_int("PVV_GRID_PER_CU", 24);
-    static const int ppw = env_int("PVV_PIX_PER_WAVE", 128);
-    static const int items_per_cu = env_int("PVV_ITEMS_PER_CU", 2);
-    const int grid2 = per_cu * num_cus(), grid4 = grid2, grid8 = grid2;
-    const float8v *recs = (const float8v *)(ws + L.recs);
-    const float2 *hyps = (const float2 *)(ws + L.hyps);
-    int *counts = (int *)(ws + L.counts);
-    const int *tn = (const int *)(ws + L.tn);
-    const FastConsts fc = fast_consts(p->inlier_thresh);
-#define PVV_LAUNCH_FAST(R)                                                                                   \
-    hipLaunchKernelGGL(k_count_fast<R>, dim3(grid##R), dim3(kBlock), 0, st, recs, hyps, counts, tn, p->B, \
-                       p->K, p->hn, p->cap, p->inlier_thresh, fc, ppw, items_per_cu * num_cus())
-    if (p->hn <= 128) PVV_LAUNCH_FAST(2);
-    else if (p->hn <= 256) PVV_LAUNCH_FAST(4);
-    else PVV_LAUNCH_FAST(8);
-#undef PVV_LAUNCH_FAST
-    return check_launch("k_count_fast");
+#else
+    (void)name;
+    return dflt;
+#endif
 }
 
 int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st)
@@ -250,17 +197,15 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     // 12-150 % slower: device-scope atomics on one address serialise at ~20 ns each; an effective grid that gives every
     // block the same NUMBER of items was 6 % slower too -- its stride (32 images' worth of items) lines the near-empty
     // last chunks of all images up in the same blocks.
-    static const int per_cu_env = env_int("PVV_GRID_PER_CU", 0);
-    static const int items_per_cu = env_int("PVV_ITEMS_PER_CU", 2);
-    const int per_cu = per_cu_env > 0 ? per_cu_env : (p->hn <= 512 ? 15 : 48);
+    const int per_cu_t = tuning_int("PVV_GRID_PER_CU", 0);
+    const int items_per_cu = tuning_int("PVV_ITEMS_PER_CU", 2);
+    const int per_cu = per_cu_t > 0 ? per_cu_t : (p->hn <= 512 ? 15 : 48);
     hipLaunchKernelGGL(k_count_bf16, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, (const float2 *)(ws + L.coords),
                        (const float2 *)(ws + L.dirs), (const float2 *)(ws + L.hyps), (int *)(ws + L.counts),
                        (const int *)(ws + L.tn), p->B, p->K, p->hn, p->cap, p->inlier_thresh,
                        bf16_consts(p->inlier_thresh), items_per_cu * num_cus());
     return check_launch("k_count_bf16");
 }
-
-int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st);
 
 CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
 {
@@ -282,34 +227,23 @@ CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
 int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st)
 {
     if (use_bf16_count(p)) return launch_count_bf16(p, L, ws, st);
-    if (use_fast_count(p->inlier_thresh)) return launch_count_fast(p, L, ws, st);
     return launch_count(planar_count_args(p, L, ws), st);
 }
 
 template <int ES>
-int launch_compaction(const MaskArgs &m, const VertexArgs &v, const Layout &L, char *ws, int B,
-                      hipStream_t st)
+void launch_scan(const MaskArgs &m, const Layout &L, char *ws, int B, hipStream_t st)
 {
-    dim3 grid(L.T, B), block(kBlock);
-    int *tile_nz = (int *)(ws + L.tile_nz), *tile_sum = (int *)(ws + L.tile_sum);
-    unsigned long long *bits = (unsigned long long *)(ws + L.bits);
-    hipLaunchKernelGGL(k_tile_count<ES>, grid, block, 0, st, m, tile_nz, tile_sum, bits);
-    if (int e = check_launch("k_tile_count")) return e;
-    if (!m.fuse_sub) {   // large images only: k_compact would redo too many draws (see there)
-        hipLaunchKernelGGL(k_tile_subsample, grid, block, 0, st, m, tile_nz, (const int *)tile_sum, bits);
-        if (int e = check_launch("k_tile_subsample")) return e;
-    }
-    hipLaunchKernelGGL(k_compact, grid, block, 0, st, m, v, (const int *)tile_nz, (const int *)tile_sum,
-                       (const unsigned long long *)bits, (int *)(ws + L.tn), (float2 *)(ws + L.coords),
-                       (float2 *)(ws + L.dirs), (PixelRec *)(ws + L.recs));
-    return check_launch("k_compact");
+    hipLaunchKernelGGL(k_tile_scan<ES>, dim3(L.T, B), dim3(kBlock), 0, st, m, (uint32_t *)(ws + L.tiles),
+                       (unsigned short *)(ws + L.tile_list));
 }
 
-// compaction + hypotheses + counting, shared by both layers
+// mask scan + (subsample) + compaction and hypotheses + counting, shared by both layers.
+// stream_first / stream_rest: RNG stream of the hypotheses [0, hn_first) / [hn_first, hn) -- 1 for
+// ransac_voting_layer_v3, 3 for the estimate, so that the two layers never share draws under one seed
 int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d_vertex,
               const int32_t *d_idxs, const float *d_selection, char *ws, const Layout &L,
               hipStream_t st, int32_t *d_tn, const float *d_seg = nullptr, int64_t *d_mask_out = nullptr,
-              const int32_t *d_idxs2 = nullptr, int hn_first = -1)
+              const int32_t *d_idxs2 = nullptr, int hn_first = -1, uint32_t stream_first = 1u, uint32_t stream_rest = 3u)
 {
     MaskArgs m;
     m.mask = d_mask;
@@ -327,34 +261,46 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
     m.seed = p->seed;
     m.b0 = p->first_image;
     m.tn_user = d_tn;
-    // ... and only when subsampling is unlikely: max_num at least 1/16 of the image (30000 of 307200).  The reference's
-    // default call (128 hypotheses on max_num = 100 pixels, resnet18.py:75) subsamples EVERY image, and redoing the
-    // draws per block cost it 35 % (783 k -> 513 k images/s)
-    m.fuse_sub = (L.T <= kFuseSubTiles && (long long)p->max_num * 16 >= (long long)p->H * p->W) ? 1 : 0;
+    // Subsampling inside k_compact_hyp (no k_tile_subsample launch) only for images of <= kFuseSubTiles tiles, only when
+    // subsampling is unlikely -- max_num at least 1/16 of the image (30000 of 307200); the reference's default call
+    // (128 hypotheses on max_num = 100 pixels, resnet18.py:75) subsamples EVERY image -- and only with the device RNG:
+    // injected index pairs address rows of the SUBSAMPLED list, which the hypothesis blocks can read off the tile lists
+    // only after k_tile_subsample has rewritten them.
+    m.fuse_sub = (L.T <= kFuseSubTiles && (long long)p->max_num * 16 >= (long long)p->H * p->W && !d_idxs && !d_idxs2) ? 1 : 0;
+    // largest possible foreground_num: the sum of byte values (P:126), of class indices (fused argmax) or of ones (P:208)
+    const long long max_weight = mode == 1 ? 1 : (d_seg ? (p->seg_classes > 1 ? p->seg_classes - 1 : 1) : 255);
+    const bool can_subsample = (long long)p->max_num < max_weight * (long long)p->H * p->W;
     VertexArgs v;
     v.vertex = d_vertex;
     v.sb = p->vertex_stride[0]; v.sh = p->vertex_stride[1]; v.sw = p->vertex_stride[2];
     v.sk = p->vertex_stride[3]; v.sc = p->vertex_stride[4];
     v.K = p->K;
-    v.kappa = use_bf16_count(p) ? 0.0 : (use_fast_count(p->inlier_thresh) ? fast_kappa_value(p->inlier_thresh) : 0.0);
     v.vec2 = (v.sc == 1 && !(v.sb & 1) && !(v.sh & 1) && !(v.sw & 1) && !(v.sk & 1) &&
               ((uintptr_t)d_vertex % 8 == 0)) ? 1 : 0;
-    int e;
     switch (m.es) {
-    case 1: e = launch_compaction<1>(m, v, L, ws, p->B, st); break;
-    case 2: e = launch_compaction<2>(m, v, L, ws, p->B, st); break;
-    case 4: e = launch_compaction<4>(m, v, L, ws, p->B, st); break;
-    default: e = launch_compaction<8>(m, v, L, ws, p->B, st); break;
+    case 1: launch_scan<1>(m, L, ws, p->B, st); break;
+    case 2: launch_scan<2>(m, L, ws, p->B, st); break;
+    case 4: launch_scan<4>(m, L, ws, p->B, st); break;
+    default: launch_scan<8>(m, L, ws, p->B, st); break;
     }
-    if (e) return e;
-
-    const long long nh = (long long)p->B * p->K * p->hn;
-    hipLaunchKernelGGL(k_gen_hypothesis, dim3((unsigned)((nh + kBlock - 1) / kBlock)), dim3(kBlock),
-                       0, st, d_idxs, d_idxs2, hn_first < 0 ? p->hn : hn_first, (const int *)(ws + L.tn),
-                       (const float2 *)(ws + L.coords),
-                       (const float2 *)(ws + L.dirs), (float2 *)(ws + L.hyps), (int *)(ws + L.counts),
-                       p->B, p->K, p->hn, p->cap, p->seed, p->first_image);
-    if ((e = check_launch("k_gen_hypothesis"))) return e;
+    if (int e = check_launch("k_tile_scan")) return e;
+    if (!m.fuse_sub && can_subsample) {
+        hipLaunchKernelGGL(k_tile_subsample, dim3(L.T, p->B), dim3(kBlock), 0, st, m, (uint32_t *)(ws + L.tiles),
+                           (unsigned short *)(ws + L.tile_list));
+        if (int e = check_launch("k_tile_subsample")) return e;
+    }
+    HypArgs h;
+    h.idxs = d_idxs; h.idxs2 = d_idxs2;
+    h.hn = p->hn; h.hn_first = hn_first < 0 ? p->hn : hn_first;
+    h.stream = stream_first; h.stream2 = stream_rest;
+    h.hyps = (float2 *)(ws + L.hyps);
+    h.counts = (int *)(ws + L.counts);
+    h.draws_out = p->d_draws_out;
+    h.blocks = (int)(((long long)p->K * p->hn + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_compact_hyp, dim3(L.T + h.blocks, p->B), dim3(kBlock), sizeof(int) * (size_t)L.T, st, m, v, h,
+                       (const uint32_t *)(ws + L.tiles), (const unsigned short *)(ws + L.tile_list),
+                       (int *)(ws + L.tn), (float2 *)(ws + L.coords), (float2 *)(ws + L.dirs));
+    if (int e = check_launch("k_compact_hyp")) return e;
     return launch_count_any(p, L, ws, st);
 }
 
@@ -455,7 +401,7 @@ PVV_EXPORT int pvv_estimate_voting_distribution(const pvv_problem *p, const void
     if (!d_mean || !d_cov) return fail(PVV_E_ARG, "d_mean / d_cov is NULL");
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)d_workspace;
-    if (int e = run_front(p, 1, d_mask, d_vertex, d_idxs, d_selection, ws, L, st, d_tn)) return e;
+    if (int e = run_front(p, 1, d_mask, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, nullptr, nullptr, nullptr, -1, 3u, 3u)) return e;
     hipLaunchKernelGGL(k_covariance, dim3(p->K, p->B), dim3(kBlock), 0, st,
                        (const int *)(ws + L.tn), (const float2 *)(ws + L.hyps),
                        (const int *)(ws + L.counts), (const float2 *)d_mean, d_cov, (float2 *)d_hyp,

@@ -209,6 +209,13 @@ const int32_t *opt_idxs(const std::optional<at::Tensor> &idxs, const at::Tensor 
     return t.data_ptr<int32_t>();
 }
 
+// Injected U(0,1) draws may let ANY number of foreground pixels survive (all zeros keep every pixel), so the rows
+// reserved per image are not bounded by max_num + 8 sigma then: reserve the whole image (call before make_workspace).
+void cap_for_selection(const std::optional<at::Tensor> &sel, pvv_problem &p)
+{
+    if (sel.has_value()) p.cap = (int32_t)std::min<int64_t>((int64_t)p.H * p.W, std::numeric_limits<int32_t>::max());
+}
+
 const float *opt_selection(const std::optional<at::Tensor> &sel, const at::Tensor &vertex, const pvv_problem &p)
 {
     if (!sel.has_value()) return nullptr;
@@ -231,12 +238,14 @@ at::Tensor make_workspace(const pvv_problem &p, const at::Tensor &like)
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> ransac_voting_v3(
     at::Tensor mask, at::Tensor vertex, int64_t round_hyp_num, double inlier_thresh, int64_t min_num,
     int64_t max_num, std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection, int64_t seed,
-    int64_t singular_policy, int64_t first_image)
+    int64_t singular_policy, int64_t first_image, int64_t count_kernel)
 {
     const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num,
                                  singular_policy, seed);
     p.first_image = (int32_t)first_image;
+    p.count_kernel = (int32_t)count_kernel;
+    cap_for_selection(selection, p);
     const int32_t *ip = opt_idxs(idxs, vertex, p);
     const float *sp = opt_selection(selection, vertex, p);
     at::Tensor ws = make_workspace(p, vertex);
@@ -268,6 +277,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_v3(
     p.first_image = (int32_t)first_image;
     p.seg_classes = (int32_t)seg.size(1);
     for (int i = 0; i < 4; ++i) p.seg_stride[i] = seg.stride(i);
+    cap_for_selection(selection, p);
     const int32_t *ip = opt_idxs(idxs, vertex, p);
     const float *sp = opt_selection(selection, vertex, p);
     at::Tensor ws = make_workspace(p, vertex);
@@ -301,6 +311,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tenso
     p.first_image = (int32_t)first_image;
     p.seg_classes = (int32_t)seg.size(1);
     for (int i = 0; i < 4; ++i) p.seg_stride[i] = seg.stride(i);
+    cap_for_selection(selection, p);
     const int32_t *ip = opt_idxs(idxs, vertex, p);
     pvv_problem pe = p;
     pe.hn = (int32_t)hyp_est;
@@ -327,11 +338,13 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tenso
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> estimate_voting_distribution(
     at::Tensor mask, at::Tensor vertex, at::Tensor mean, int64_t hyp_total, double inlier_thresh,
     int64_t min_num, int64_t max_num, std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection,
-    int64_t seed, bool want_hyp, int64_t first_image)
+    int64_t seed, bool want_hyp, int64_t first_image, int64_t count_kernel)
 {
     const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     pvv_problem p = make_problem(mask, vertex, hyp_total, inlier_thresh, min_num, max_num, 0, seed);
     p.first_image = (int32_t)first_image;
+    p.count_kernel = (int32_t)count_kernel;
+    cap_for_selection(selection, p);
     check_dev(mean, "mean", at::kFloat);
     same_device(vertex, mean, "mean");
     TORCH_CHECK(mean.dim() == 3 && mean.size(0) == p.B && mean.size(1) == p.K && mean.size(2) == 2,
@@ -389,7 +402,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     namespace py = pybind11;
     m.def("ransac_voting_v3", &ransac_voting_v3, "batched ransac_voting_layer_v3", py::arg("mask"), py::arg("vertex"),
           py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"), py::arg("idxs"),
-          py::arg("selection"), py::arg("seed"), py::arg("singular_policy"), py::arg("first_image") = 0);
+          py::arg("selection"), py::arg("seed"), py::arg("singular_policy"), py::arg("first_image") = 0,
+          py::arg("count_kernel") = 0);
     m.def("decode_keypoint_v3", &decode_keypoint_v3, "argmax(seg) fused with batched ransac_voting_layer_v3",
           py::arg("seg"), py::arg("vertex"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"),
           py::arg("max_num"), py::arg("idxs"), py::arg("selection"), py::arg("seed"), py::arg("singular_policy"),
@@ -402,10 +416,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("estimate_voting_distribution", &estimate_voting_distribution,
           "batched estimate_voting_distribution_with_mean", py::arg("mask"), py::arg("vertex"), py::arg("mean"),
           py::arg("hyp_total"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"), py::arg("idxs"),
-          py::arg("selection"), py::arg("seed"), py::arg("want_hyp"), py::arg("first_image") = 0);
+          py::arg("selection"), py::arg("seed"), py::arg("want_hyp"), py::arg("first_image") = 0, py::arg("count_kernel") = 0);
     m.def("rerun_count_kernel", &rerun_count_kernel, "re-launch the inlier-count kernel (profiling aid)");
     m.attr("abi_version") = pvv_abi_version();
     m.attr("SINGULAR_REFERENCE") = (int)PVV_SINGULAR_REFERENCE;
     m.attr("SINGULAR_ZERO") = (int)PVV_SINGULAR_ZERO;
     m.attr("SINGULAR_IMAGE_ZERO") = (int)PVV_SINGULAR_IMAGE_ZERO;
+    m.attr("COUNT_AUTO") = (int)PVV_COUNT_AUTO;
+    m.attr("COUNT_EXACT") = (int)PVV_COUNT_EXACT;
 }

@@ -53,5 +53,10 @@ def sharded_vote(vote_fn, mask_local, vertex_local, batch, *args, group=None, se
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         rank = dist.get_rank(group) if world > 1 else 0
         kwargs = dict(kwargs, seed=int(seed), first_image=shard_bounds(batch, world, rank)[0])
-    local = vote_fn(mask_local, vertex_local, *args, **kwargs)
+    if vertex_local.shape[0] == 0:
+        # a trailing rank of an uneven split (batch=9 on 8 GPUs leaves ranks 5-7 without an image) still has to enter
+        # the collective: zero rows of the layer's result shape, no launch
+        local = vertex_local.new_zeros((0, vertex_local.shape[3], 2))
+    else:
+        local = vote_fn(mask_local, vertex_local, *args, **kwargs)
     return gather_results(local, batch, group)

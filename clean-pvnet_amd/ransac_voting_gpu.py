@@ -56,6 +56,8 @@ def _chunks(b):
 def _vote_v3(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, idxs, selection, policy, seed=None,
              first_image=0):
     b = vertex.shape[0]
+    if b == 0:                      # an empty shard (dist.sharded_vote on a trailing rank): nothing to launch
+        return vertex.new_zeros((0, vertex.shape[3], 2))
     mask = _as_mask(mask, False)
     outs = []
     seed = _next_seed() if seed is None else int(seed)   # one key for the whole batch; the device RNG is keyed by (seed, image index), so the
@@ -145,6 +147,12 @@ def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256
     '''
     del topk
     b = vertex.shape[0]
+    if b == 0:
+        empty = (mean, vertex.new_zeros((0, vertex.shape[3], 2, 2)))
+        if output_hyp:
+            hn0 = int(np.ceil(min_hyp_num / round_hyp_num)) * int(round_hyp_num)
+            empty += (vertex.new_zeros((0, vertex.shape[3], hn0, 2)), vertex.new_zeros((0, vertex.shape[3], hn0)))
+        return empty + ((vertex.new_zeros((0, vertex.shape[3], 3)),) if return_weights else ())
     hn_total = int(np.ceil(min_hyp_num / round_hyp_num)) * int(round_hyp_num)
     mask = _as_mask(mask, True)
     mean_c = mean.contiguous().float()

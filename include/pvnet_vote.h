@@ -30,7 +30,7 @@ extern "C" {
 #define PVV_E_WORKSPACE (-2) /* workspace smaller than pvv_workspace_bytes() */
 
 /* ABI version of this header; pvv_abi_version() must return the same. */
-#define PVV_ABI_VERSION 4
+#define PVV_ABI_VERSION 5
 
 int pvv_abi_version(void);
 const char *pvv_last_error(void);
@@ -106,7 +106,21 @@ typedef struct pvv_problem {
                                 numbers as one call.  0 for a whole batch (was reserved_, keep 0 if unsure) */
     int64_t seg_stride[4];   /* element strides of seg [B,C,H,W] (a channel slice
                                 of the network output, resnet18.py:93)          */
+    /* ---- ABI v5 ---- */
+    int32_t count_kernel;    /* PVV_COUNT_*: which inlier-count kernel runs; 0 (AUTO) unless cross-checking */
+    int32_t reserved0;       /* keep 0 */
+    int32_t *d_draws_out;    /* optional DEVICE buffer [B,K,hn,2] i32 (NULL = off): the pixel (y*W + x) each
+                                hypothesis' index pair resolved to, -1 where none (image skipped).  Lets a test
+                                replay the device RNG's draws through the oracle; for the fused un_pnp call hn is
+                                p->hn + hn_est */
 } pvv_problem;
+
+/* pvv_problem.count_kernel.  AUTO: the split-bf16 matrix-core prefilter with its guard band wherever it is valid
+ * (0.5 <= inlier_thresh <= 0.99995, H and W <= 16384), the exact kernel elsewhere.  EXACT: the reference's own
+ * arithmetic (sqrt, divide) for every evaluation -- identical counts, ~9x slower; what the tests cross-check AUTO
+ * against.  (Round 1 selected this with an environment variable; the library now reads no environment.) */
+#define PVV_COUNT_AUTO 0
+#define PVV_COUNT_EXACT 1
 
 /* b_inv (P:97-109) falls back to the identity for the WHOLE image when the
  * batched solve raises; REFERENCE reproduces that (x = ATb for every keypoint

@@ -19,7 +19,8 @@ class Problem(ctypes.Structure):
                 ("mask_elem_size", c_i32), ("min_num", c_i32), ("max_num", c_i32), ("cap", c_i32),
                 ("singular_policy", c_i32), ("inlier_thresh", c_f32),
                 ("mask_stride", c_i64 * 3), ("vertex_stride", c_i64 * 5), ("seed", c_u64),
-                ("seg_classes", c_i32), ("first_image", c_i32), ("seg_stride", c_i64 * 4)]
+                ("seg_classes", c_i32), ("first_image", c_i32), ("seg_stride", c_i64 * 4),
+                ("count_kernel", c_i32), ("reserved0", c_i32), ("d_draws_out", vp)]
 
 
 def declared_symbols():
@@ -56,14 +57,18 @@ def load():
     return _lib
 
 
-def problem(mask, vertex, hn, thresh, min_num=5, max_num=30000, policy=0, seed=0):
+def problem(mask, vertex, hn, thresh, min_num=5, max_num=30000, policy=0, seed=0, count_kernel=0, draws_out=None,
+            first_image=0, cap=None):
     L = load()
     p = Problem()
     p.B, p.H, p.W, p.K, _ = vertex.shape
     p.hn = hn
     p.mask_elem_size = mask.element_size()
     p.min_num, p.max_num = min_num, max_num
-    p.cap = L.pvv_default_cap(p.H, p.W, max_num)
+    p.cap = L.pvv_default_cap(p.H, p.W, max_num) if cap is None else cap
+    p.count_kernel = count_kernel
+    p.first_image = first_image
+    p.d_draws_out = None if draws_out is None else draws_out.data_ptr()
     p.singular_policy = policy
     p.inlier_thresh = thresh
     p.mask_stride[:] = mask.stride()
@@ -89,6 +94,8 @@ def v3(mask, vertex, hn, thresh, idxs=None, selection=None, **kw):
     """pvv_ransac_voting_v3 on torch CUDA tensors -> (out [B,K,2], win_counts [B,K], tn [B])."""
     import torch
     L = load()
+    if selection is not None:      # injected draws may keep any number of pixels: reserve the whole image (as the pybind shim does)
+        kw.setdefault("cap", vertex.shape[1] * vertex.shape[2])
     p = problem(mask, vertex, hn, thresh, **kw)
     n = L.pvv_workspace_bytes(ctypes.byref(p))
     assert n > 0, L.pvv_last_error()
@@ -105,6 +112,8 @@ def v3(mask, vertex, hn, thresh, idxs=None, selection=None, **kw):
 def estimate(mask, vertex, mean, hn_total, thresh, idxs=None, selection=None, **kw):
     import torch
     L = load()
+    if selection is not None:
+        kw.setdefault("cap", vertex.shape[1] * vertex.shape[2])
     p = problem(mask, vertex, hn_total, thresh, **kw)
     n = L.pvv_workspace_bytes(ctypes.byref(p))
     assert n > 0, L.pvv_last_error()

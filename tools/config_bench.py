@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""Every BASELINE config (and the shards / default path the verdicts ask about) on ONE MI355X, one JSON file:
+
+    gpurun -- 'python tools/config_bench.py --out gpurun_out/<dir>/configs.json'
+    cp gpurun_out/<dir>/configs.json profiles/rNN_configs.json
+
+Per row: images/s and ms per call of ``ransac_voting_layer_v3`` through the drop-in Python API measured three ways
+(host wall clock over back-to-back calls; per-call HIP events on the launch stream: median / p10 / p90; one captured
+HIP graph replayed back to back = the GPU-side floor without host launch cost), the host-only cost of a call (calls
+enqueued without waiting, on an idle stream), the inlier-count kernel's duration (re-launches between HIP events),
+evaluations/s and the dense-field roofline fraction of that kernel.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+ROWS = [
+    # name, config, B, overrides
+    ("cfg2_B1", "cfg2", 1, {}),
+    ("cfg3_B2", "cfg3", 2, {}),
+    ("cfg3_B4", "cfg3", 4, {}),
+    ("cfg3_B8_shard_of_8gpu", "cfg3", 8, {}),
+    ("cfg3_B16", "cfg3", 16, {}),
+    ("cfg3_B32", "cfg3", 32, {}),
+    ("cfg3_B64", "cfg3", 64, {}),
+    ("cfg4_B32", "cfg4", 32, {}),
+    ("cfg4_B4_shard_of_8gpu", "cfg4", 4, {}),
+    ("cfg5_B16", "cfg5", 16, {}),
+    ("cfg5_B2_shard_of_8gpu", "cfg5", 2, {}),
+    ("default_path_hn128_maxnum100_B64", "cfg3", 64, {"hn": 128, "max_num": 100}),
+    ("default_path_hn128_maxnum100_B1", "cfg3", 1, {"hn": 128, "max_num": 100}),
+]
+
+
+def pct(v, q):
+    v = sorted(v)
+    return v[min(len(v) - 1, int(q * len(v)))]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="")
+    ap.add_argument("--rows", default="", help="comma-separated row names (default: all)")
+    ap.add_argument("--calls", type=int, default=200)
+    args = ap.parse_args()
+    import lib
+    lib._register_clean_pvnet_amd()
+    from clean_pvnet_amd import ransac_voting as ext
+    from clean_pvnet_amd import synth
+    from lib.csrc.ransac_voting.ransac_voting_gpu import ransac_voting_layer_v3
+    dev = torch.device("cuda:0")
+    want = set(args.rows.split(",")) if args.rows else None
+    res = {"device": torch.cuda.get_device_name(0), "rows": {}}
+    for name, cfgname, B, over in ROWS:
+        if want and name not in want:
+            continue
+        cfg = dict(synth.CONFIGS[cfgname])
+        H, W, K = cfg["H"], cfg["W"], cfg["K"]
+        hn = over.get("hn", cfg["hn"])
+        max_num = over.get("max_num", 30000)
+        gen = {k: v for k, v in cfg.items() if k not in ("B", "hn")}
+        d = synth.make_batch(B=B, **gen, device=dev)
+        mask, vertex = d["mask"], d["vertex"]
+        n = args.calls if B <= 16 else max(20, args.calls // 4)
+
+        def call():
+            return ransac_voting_layer_v3(mask, vertex, hn, inlier_thresh=0.99, max_num=max_num)
+
+        for _ in range(10):
+            out = call()
+        torch.cuda.synchronize()
+        # (a) host wall clock over back-to-back calls
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = call()
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        # (b) per-call HIP events
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        evs[0].record()
+        for i in range(n):
+            call()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        per = [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
+        # (c) host-only cost of a call: enqueue on an idle stream, no waiting (small bursts so the queue never fills)
+        host = []
+        for _ in range(10):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(8):
+                call()
+            host.append((time.perf_counter() - t1) / 8)
+        torch.cuda.synchronize()
+        # (d) one captured graph replayed back to back
+        graph_ms = None
+        try:
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    call()
+                with torch.cuda.graph(g, stream=s):
+                    gout = call()
+            for _ in range(5):
+                g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            graph_ms = e0.elapsed_time(e1) / n
+            del g, gout
+        except Exception as ex:  # noqa: BLE001
+            graph_ms = "failed: %s" % (str(ex)[:100],)
+        # (e) the count kernel alone
+        _o, win, tn, ws = ext.ransac_voting_v3(mask, vertex, hn, 0.99, 5, max_num, None, None, 1, ext.SINGULAR_REFERENCE)
+        for _ in range(3):
+            ext.rerun_count_kernel(mask, vertex, hn, 0.99, 5, max_num, ws, False)
+        groups, per_group = 5, 10
+        kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(groups)]
+        for a, b in kev:
+            a.record()
+            for _ in range(per_group):
+                ext.rerun_count_kernel(mask, vertex, hn, 0.99, 5, max_num, ws, False)
+            b.record()
+        torch.cuda.synchronize()
+        k_ms = sum(a.elapsed_time(b) / per_group for a, b in kev) / groups
+        tn_sum = int(tn.sum().item())
+        evals = tn_sum * K * hn
+        alg = synth.dense_field_bytes(B, H, W, K, hn)
+        err = float((out - d["kpt_2d"]).abs().max())
+        row = {"B": B, "H": H, "W": W, "K": K, "hn": hn, "max_num": max_num, "tn_mean": round(tn_sum / B, 1),
+               "calls": n,
+               "wall_ms_per_call": round(1e3 * wall / n, 4), "images_per_s_wall": round(B * n / wall, 1),
+               "host_enqueue_ms_per_call_backlogged": round(1e3 * t_enq / n, 4),
+               "host_ms_per_call_idle_stream": round(1e3 * sorted(host)[len(host) // 2], 4),
+               "event_ms_per_call_median": round(pct(per, 0.5), 4), "event_ms_p10": round(pct(per, 0.1), 4),
+               "event_ms_p90": round(pct(per, 0.9), 4),
+               "graph_replay_ms_per_call": round(graph_ms, 4) if isinstance(graph_ms, float) else graph_ms,
+               "count_kernel_ms": round(k_ms, 4), "evaluations": evals,
+               "tevals_per_s": round(evals / (k_ms * 1e-3) / 1e12, 2),
+               "dense_field_bytes": alg, "roofline_frac_hbm_8TBs": round(alg / (k_ms * 1e-3) / 8e12, 4),
+               "known_answer_max_err_px": round(err, 3)}
+        res["rows"][name] = row
+        print(name, json.dumps(row), flush=True)
+        del d, mask, vertex, ws
+        torch.cuda.empty_cache()
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        json.dump(res, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
