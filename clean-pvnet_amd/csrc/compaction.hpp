@@ -9,7 +9,9 @@
 //
 // The image is cut into tiles of kTile = 2048 consecutive pixels.  k_tile_scan -- the ONLY pass over the mask --
 // leaves per tile (i) one packed word: foreground pixels | weight sum << 12 (foreground_num of P:126 sums byte
-// VALUES), (ii) the tile's foreground pixels as an ordered list of 16-bit offsets.  Everything downstream works from
+// VALUES), (ii) the tile's foreground pixels as an ordered list of 16-bit offsets and -- when subsampling is possible
+// -- (iii) each listed pixel's U(0,1) draw of P:136 / P:220 (injected or from the counter RNG keyed by (image, pixel)),
+// so that no later stage evaluates the generator or touches the selection tensor again.  Everything downstream works from
 // those lists: the subsample (k_tile_subsample, or fused into k_compact_hyp) filters them, the compaction blocks of
 // k_compact_hyp gather the vertex field through them, and its hypothesis blocks pick the t-th foreground pixel of an
 // image by a search in the tile prefix + ONE list read -- so hypotheses need not wait for the compaction and the
@@ -28,6 +30,8 @@ struct MaskArgs {
     int b0;                  // first_image: RNG key offset of image 0
     int *tn_user;            // the caller's tn[B] (or nullptr): written beside the workspace copy, no D2D copy later
     int fuse_sub;            // 1: k_compact_hyp applies the subsampling itself (no k_tile_subsample launch), see there
+    int want_draws;          // 1: subsampling is possible at all (max_num below the largest foreground_num the mask can
+                             //    have): k_tile_scan stores every foreground pixel's U(0,1) draw beside its list entry
     // fused argmax (decode_keypoint): when seg != nullptr the mask value is argmax_c seg[b,c,y,x]
     const float *seg;
     long long *mask_out;     // [B,H,W] int64 or nullptr
@@ -113,7 +117,8 @@ __device__ __forceinline__ void scan_segments(int *seg)
 // Pass 1 -- the ONLY pass that reads the mask.
 template <int ES>
 __global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__restrict__ tiles,
-                                                      unsigned short *__restrict__ tile_list)
+                                                      unsigned short *__restrict__ tile_list,
+                                                      float *__restrict__ tile_draw)
 {
     __shared__ int seg[kTileSteps * 4 + 1];
     __shared__ int red[4];
@@ -136,10 +141,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__re
     if (threadIdx.x == 0)
         tiles[b * a.T + t] = (uint32_t)seg[kTileSteps * 4] | ((uint32_t)(red[0] + red[1] + red[2] + red[3]) << 12);
     unsigned short *list = tile_list + ((size_t)b * a.T + t) * kTile;
+    float *draw = tile_draw + ((size_t)b * a.T + t) * kTile;
 #pragma unroll
     for (int s = 0; s < kTileSteps; ++s)
-        if ((m[s] >> lane) & 1ull)
-            list[seg[s * 4 + wave] + __popcll(m[s] & ((1ull << lane) - 1ull))] = (unsigned short)(s * kBlock + threadIdx.x);
+        if ((m[s] >> lane) & 1ull) {
+            const int r = seg[s * 4 + wave] + __popcll(m[s] & ((1ull << lane) - 1ull));
+            list[r] = (unsigned short)(s * kBlock + threadIdx.x);
+            if (a.want_draws) draw[r] = selection_draw(a, b, t * kTile + s * kBlock + threadIdx.x);
+        }
 }
 
 // foreground_num of P:126 / P:208 (sum of the weights) and the number of foreground pixels of image b.
@@ -175,8 +184,8 @@ __device__ __forceinline__ ImageTotals image_totals(const uint32_t *__restrict__
 
 // Filter one tile's list by the subsample draw (keep iff U < prob), order kept: survivors land in out[] (LDS or
 // global, may alias nothing), their number is returned to every thread.  seg: kTileSteps*4+1 ints of LDS.
-__device__ __forceinline__ int filter_tile_list(const MaskArgs &a, int b, int t, int nz, float prob,
-                                                const unsigned short *__restrict__ list, unsigned short *out, int *seg)
+__device__ __forceinline__ int filter_tile_list(int nz, float prob, const unsigned short *__restrict__ list,
+                                                const float *__restrict__ draw, unsigned short *out, int *seg)
 {
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     unsigned long long m[kTileSteps];
@@ -188,7 +197,7 @@ __device__ __forceinline__ int filter_tile_list(const MaskArgs &a, int b, int t,
         off[s] = 0;
         if (e < nz) {
             off[s] = list[e];
-            f = selection_draw(a, b, t * kTile + off[s]) < prob;
+            f = draw[e] < prob;
         }
         m[s] = __ballot(f);
         if (lane == 0) seg[s * 4 + wave] = __popcll(m[s]);
@@ -205,7 +214,8 @@ __device__ __forceinline__ int filter_tile_list(const MaskArgs &a, int b, int t,
 // quotient).  Rewrites the tile's list in place and its count; tiles without foreground and images that are not
 // subsampled exit at once.
 __global__ __launch_bounds__(kBlock) void k_tile_subsample(MaskArgs a, uint32_t *__restrict__ tiles,
-                                                           unsigned short *__restrict__ tile_list)
+                                                           unsigned short *__restrict__ tile_list,
+                                                           const float *__restrict__ tile_draw)
 {
     __shared__ long long redl[4];
     __shared__ int red[8];
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_subsample(MaskArgs a, uint32_t 
     if (tot.fg <= (long long)a.max_num) return;
     const float prob = (float)a.max_num / (float)tot.fg;
     unsigned short *list = tile_list + ((size_t)b * a.T + t) * kTile;
-    const int n = filter_tile_list(a, b, t, nz, prob, list, keep, seg);
+    const int n = filter_tile_list(nz, prob, list, tile_draw + ((size_t)b * a.T + t) * kTile, keep, seg);
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += kBlock) list[i] = keep[i];
     // In place: the other blocks of the image may still be reading the table, but they only use the weight sums
@@ -259,7 +269,8 @@ constexpr int kHypRejectTries = 1 << 12;
 
 // Row t of the image's (not yet written) compacted list -> pixel: search the inclusive tile prefix, then one read of
 // the tile's list.
-__device__ __forceinline__ int select_pixel(const int *prefix, int T, const unsigned short *__restrict__ lists /*of image b*/, int t)
+__device__ __forceinline__ int select_pixel(const int *prefix, int T, const unsigned short *__restrict__ lists /*of image b*/, int t,
+                                            size_t *entry = nullptr /*index of the list entry within the image's lists*/)
 {
     int lo = 0, hi = T - 1;               // smallest i with prefix[i] > t
     while (lo < hi) {
@@ -267,7 +278,9 @@ __device__ __forceinline__ int select_pixel(const int *prefix, int T, const unsi
         if (prefix[mid] > t) hi = mid; else lo = mid + 1;
     }
     const int r = t - (lo ? prefix[lo - 1] : 0);
-    return lo * kTile + (int)lists[(size_t)lo * kTile + r];
+    const size_t e = (size_t)lo * kTile + r;
+    if (entry) *entry = e;
+    return lo * kTile + (int)lists[e];
 }
 
 // Ordered scatter + hypotheses, one launch, grid (T + h.blocks, B):
@@ -279,6 +292,7 @@ __device__ __forceinline__ int select_pixel(const int *prefix, int T, const unsi
 __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v, HypArgs h,
                                                         const uint32_t *__restrict__ tiles,
                                                         const unsigned short *__restrict__ tile_list,
+                                                        const float *__restrict__ tile_draw,
                                                         int *__restrict__ tn_out, float2 *__restrict__ coords,
                                                         float2 *__restrict__ dirs)
 {
@@ -290,6 +304,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
     const int b = blockIdx.y;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const unsigned short *img_lists = tile_list + (size_t)b * a.T * kTile;
+    const float *img_draws = tile_draw + (size_t)b * a.T * kTile;
 
     if ((int)blockIdx.x >= a.T) {
         // ------------------------------------------------------------------ hypothesis block
@@ -363,15 +378,16 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
                 p0 = p1 = -1;
                 for (int tr = 0; tr < kHypRejectTries && (p0 < 0 || p1 < 0); ++tr) {
                     // try tr of draw c: key (stream + 16, image, c + tr * 2^24)  -- hn * K * 2 < 2^24 (validate())
+                    size_t e;
                     if (p0 < 0) {
                         const int p = select_pixel(s_prefix, a.T, img_lists,
-                                                   (int)(rng_u32(a.seed, stream + 16u, img, c + ((uint32_t)tr << 24)) % (uint32_t)total));
-                        if (selection_draw(a, b, p) < prob) p0 = p;
+                                                   (int)(rng_u32(a.seed, stream + 16u, img, c + ((uint32_t)tr << 24)) % (uint32_t)total), &e);
+                        if (img_draws[e] < prob) p0 = p;
                     }
                     if (p1 < 0) {
                         const int p = select_pixel(s_prefix, a.T, img_lists,
-                                                   (int)(rng_u32(a.seed, stream + 16u, img, c + 1u + ((uint32_t)tr << 24)) % (uint32_t)total));
-                        if (selection_draw(a, b, p) < prob) p1 = p;
+                                                   (int)(rng_u32(a.seed, stream + 16u, img, c + 1u + ((uint32_t)tr << 24)) % (uint32_t)total), &e);
+                        if (img_draws[e] < prob) p1 = p;
                     }
                 }
                 if (p0 < 0 || p1 < 0) {                            // no survivor found (prob ~ 0): degenerate pair
@@ -420,13 +436,13 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
         int cnt = 0;
         for (int i = 0; i < t; ++i) {
             const int ni = (int)(tiles[b * a.T + i] & kTileNzMask);                 // block-uniform
-            const unsigned short *li = img_lists + (size_t)i * kTile;
+            const float *di = img_draws + (size_t)i * kTile;
             for (int e = threadIdx.x; e < ni; e += kBlock)
-                cnt += selection_draw(a, b, i * kTile + li[e]) < prob ? 1 : 0;
+                cnt += di[e] < prob ? 1 : 0;
         }
         before = block_sum(cnt, red);
         __syncthreads();
-        tile_n = filter_tile_list(a, b, t, nz, prob, my_list, list, seg);
+        tile_n = filter_tile_list(nz, prob, my_list, img_draws + (size_t)t * kTile, list, seg);
         __syncthreads();
         if (t == a.T - 1 && threadIdx.x == 0) {                                    // the last tile knows the subsampled total
             const int all = before + tile_n;

@@ -60,14 +60,53 @@ __device__ __forceinline__ void split3(float x, __bf16 (&p)[3])
     p[2] = (__bf16)r;
 }
 
+// B operand of hypothesis i of a group: lane l of tile ht holds column l%32, k = 8*(l/32)..+7 of
+//   (qx0,qy0,qx1,qx2,qx0,qy1,qy2,qy0 || qx0,qy0,qx1,qy1, 1,1,1,0),   q = pieces of h' = fl(h - o);
+// zeroes the hypothesis' LDS counter (flushed by the same thread later).  Returns 1 for a hypothesis that is non-finite
+// or astronomically far (the whole group then takes the exact loop).
+__device__ __forceinline__ int stage_hypothesis(bf16x8 *sB, int *sCnt, int i, float2 hp, float2 org)
+{
+    __bf16 qx[3], qy[3];
+    split3(hp.x - org.x, qx);
+    split3(hp.y - org.y, qy);
+    const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
+    const bf16x8 lo8 = {qx[0], qy[0], qx[1], qx[2], qx[0], qy[1], qy[2], qy[0]};
+    const bf16x8 hi8 = {qx[0], qy[0], qx[1], qy[1], one, one, one, zero};
+    sB[(i >> 5) * 64 + (i & 31)] = lo8;
+    sB[(i >> 5) * 64 + 32 + (i & 31)] = hi8;
+    sCnt[i] = 0;
+    return !(fabsf(hp.x) < 1e15f && fabsf(hp.y) < 1e15f);
+}
+
+// phase timestamps of a few blocks, instrumented builds only (tools/build_variant.sh -DPVV_TUNING -DPVV_STAMPS +
+// tools/phase_stamps.py); they cost registers, so timing sweeps use -DPVV_TUNING alone
+#ifdef PVV_STAMPS
+#define PVV_STAMP(i) do { if (dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 97 || blockIdx.x == 401)) \
+    dbg[((blockIdx.x == 0 ? 0 : (blockIdx.x == 97 ? 1 : 2)) * 16) + (i)] = wall_clock64(); } while (0)
+// per-block census behind the three timelines: dbg[64 + 4*block + {0,1,2,3}] = entry time, exit time, hardware id
+// (HW_ID | XCC_ID << 32), items processed
+#define PVV_CENSUS_IN() do { if (dbg && threadIdx.x == 0) { dbg[64 + 4 * blockIdx.x] = wall_clock64(); \
+    dbg[64 + 4 * blockIdx.x + 2] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32); } } while (0)
+#define PVV_CENSUS_OUT(n) do { if (dbg && threadIdx.x == 0) { dbg[64 + 4 * blockIdx.x + 1] = wall_clock64(); \
+    dbg[64 + 4 * blockIdx.x + 3] = (n); } } while (0)
+#else
+#define PVV_STAMP(i) do { } while (0)
+#define PVV_CENSUS_IN() do { } while (0)
+#define PVV_CENSUS_OUT(n) do { } while (0)
+#endif
+
 // 5 blocks (= 5 waves per SIMD) per CU: <= 96 VGPRs and 30 KB of LDS per block; measured -4.4 % against 4
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_count_bf16(
     const float2 *__restrict__ coords /*[B,cap]*/, const float2 *__restrict__ dirs /*[B,K,cap]*/,
     const float2 *__restrict__ hyps /*[B,K,hn]*/, int *__restrict__ counts /*[B,K,hn]*/,
-    const int *__restrict__ tn_arr, int B, int K, int hn, int cap, float thresh, Bf16Consts fc, int target_items)
+    const int *__restrict__ tn_arr, int B, int K, int hn, int cap, float thresh, Bf16Consts fc, int target_items,
+    long long *__restrict__ dbg /*tuning builds: phase timestamps; nullptr otherwise*/)
 {
-    __shared__ int item_end[kMaxBatchLds];
-    __shared__ int s_htpi, s_gpi;
+    PVV_STAMP(0);
+    PVV_CENSUS_IN();
+    int n_items_done = 0;
+    __shared__ int chunk_end[kMaxBatchLds];         // inclusive prefix of the 512-pixel chunks per image
+    __shared__ int s_htpi, s_gpi, s_chunks;
     __shared__ bf16x8 sB[kBfMaxHt * 64];            // B operands of the current hypothesis group (16 KB)
     __shared__ float4 sP[4 * kBfPixPerWave];        // per pixel: (nhx, nhy, c'x, c'y); nhx = NaN: can never vote  (8 KB)
     __shared__ int sCnt[kBfMaxHt * 32];
@@ -79,44 +118,81 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     // Work item = (image, keypoint, 512-pixel chunk, a run of hypothesis groups).  A group is up to 16 tiles (512
     // hypotheses, what fits the LDS staging); an item walks as many groups as possible (the pixel operands are
     // built once per item), fewer -- and smaller groups -- when the batch is too small to fill the chip.
+    // ONE pass over tn[] by wave 0 gives the chunk prefix of the images (the item table: every block derives the same
+    // one, no host sync) and, from the total, the item size.
     if (wave == 0) {
-        long long chunks = 0;
-        for (int b = lane; b < B; b += 64) chunks += (tn_arr[b] + PC - 1) / PC;
-        chunks = wave_sum(chunks) * K;
+        int carry = 0;
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            const int b = b0 + lane;
+            int inc = b < B ? (tn_arr[b] + PC - 1) / PC : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int m = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += m;
+            }
+            inc += carry;
+            if (b < B) chunk_end[b] = inc;
+            carry = __builtin_amdgcn_readlane(inc, 63);
+        }
+        const long long chunks = (long long)carry * K;
         int htpi = min(nt, kBfMaxHt);
         int nhg = (nt + htpi - 1) / htpi;
         int gpi = nhg;                                              // groups per item
         while (gpi > 1 && chunks * ((nhg + gpi - 1) / gpi) < target_items) gpi = (gpi + 1) >> 1;
         if (gpi == 1)
             while (htpi > 2 && chunks * ((nt + htpi - 1) / htpi) < target_items) htpi = (htpi + 1) >> 1;
-        if (lane == 0) { s_htpi = htpi; s_gpi = gpi; }
+        if (lane == 0) { s_htpi = htpi; s_gpi = gpi; s_chunks = carry; }
     }
     __syncthreads();
+    PVV_STAMP(1);
     const int htpi = __builtin_amdgcn_readfirstlane(s_htpi);
     const int gpi = __builtin_amdgcn_readfirstlane(s_gpi);
     const int nhg = (nt + htpi - 1) / htpi;          // hypothesis groups per keypoint
     const int nruns = (nhg + gpi - 1) / gpi;         // runs of groups = items per (chunk, keypoint)
     const int per_chunk = K * nruns;
-
-    const int total = build_item_table(item_end, tn_arr, 0, B, PC, per_chunk);
+    const int total = __builtin_amdgcn_readfirstlane(s_chunks) * per_chunk;
     const int col = lane & 31, kslice = lane >> 5;
+    PVV_STAMP(2);
 
     for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        const int gchunk = item / per_chunk;                    // chunk index over the whole batch
+        const int rem = item - gchunk * per_chunk;
         int local;
-        const int b = locate_item(item_end, B, item, &local);
-        const int chunk = local / per_chunk;
-        const int rem = local - chunk * per_chunk;
+        const int b = locate_item(chunk_end, B, gchunk, &local);   // image, and the chunk's index within it
+        const int chunk = local;
         const int vi = rem / nruns;
         const int run = rem - vi * nruns;
-        const int tn = __builtin_amdgcn_readfirstlane(tn_arr[b]);
         const int bk = b * K + vi;
         const float2 *hyp_k = hyps + (size_t)bk * hn;
         const float2 *crd = coords + (size_t)b * cap;
         const float2 *dir_k = dirs + (size_t)bk * cap;
         const int pb = chunk * PC;                              // first pixel of the block's chunk (< tn)
+        const int g0 = run * gpi, g1 = min(nhg, g0 + gpi);
 
         __syncthreads();                                        // previous item's LDS fully consumed
+        PVV_STAMP(3);
+        ++n_items_done;
+        // ---- every global load of the item is issued here, before anything waits: tn, the chunk's origin, two pixels
+        //      per thread (rows beyond tn are read -- the arrays reserve cap rows -- and masked below) and the
+        //      hypotheses of the first group.  One memory round trip instead of three.
+        const int tn_v = tn_arr[b];
         const float2 org = crd[pb];                             // integer origin: the chunk's first pixel
+        float2 pc[2], pd[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = min(pb + (int)threadIdx.x + q * kBlock, cap - 1);
+            pc[q] = crd[p];
+            pd[q] = dir_k[p];
+        }
+        const int nht0 = min(nt, (g0 + 1) * htpi) - g0 * htpi;  // tiles of the first group
+        float2 hp0[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = threadIdx.x + q * kBlock;
+            const int h = (g0 * htpi + (i >> 5)) * 32 + (i & 31);
+            hp0[q] = (i < nht0 * 32 && h < hn) ? hyp_k[h] : make_float2(0.f, 0.f);
+        }
+        const int tn = __builtin_amdgcn_readfirstlane(tn_v);
 
         // ---- per pixel (two per thread): the f32 unit normal and the translated coordinates (16 bytes of LDS; the
         //      kappa-scaled perpendicular and the constants -(c-o).nh, -(c-o).B are formed where they are used).  A pixel
@@ -128,7 +204,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             const int pl = threadIdx.x + q * kBlock, p = pb + pl;
             float4 rec = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
             if (p < tn) {
-                const float2 c = crd[p], d = dir_k[p];
+                const float2 c = pc[q], d = pd[q];
                 const float cx = c.x - org.x, cy = c.y - org.y;  // exact (integers)
                 c1 = fmaxf(c1, fabsf(cx) + fabsf(cy));
                 const float norm1 = sqrtf(d.x * d.x + d.y * d.y);
@@ -144,7 +220,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         c1 = fmaxf(c1, __shfl_xor(c1, 2, 64));
         c1 = fmaxf(c1, __shfl_xor(c1, 1, 64));
         if (lane == 0) sRed[wave] = c1;
-        __syncthreads();
+        // ---- B operands of the first group (see stage_group below for the layout)
+        int far = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = threadIdx.x + q * kBlock;
+            if (i < nht0 * 32) far |= stage_hypothesis(sB, sCnt, i, hp0[q], org);
+        }
+        far = __syncthreads_or(far);
+        PVV_STAMP(4);
         const float C1 = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
         const float eps = fc.eps0 + fc.eps_c * C1;
         const float epsw = __builtin_fmaf(fc.beta * 1.02f, C1, eps);   // band half-width at |h'| = 0
@@ -195,32 +279,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 A[4 + i] = __builtin_bit_cast(bf16x8, y);
             }
         }
+        PVV_STAMP(5);
         const int ebase = kslice * 4;                            // this lane's pixels: ebase + e%4 + 8*(e/4)
         const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-        const int g0 = run * gpi, g1 = min(nhg, g0 + gpi);
         for (int g = g0; g < g1; ++g) {
             const int ht0 = g * htpi;
             const int nht = min(nt, ht0 + htpi) - ht0;
-            // ---- B operands of this group: lane l of tile ht holds column l%32, k = 8*(l/32)..+7 of
-            //      (qx0,qy0,qx1,qx2,qx0,qy1,qy2,qy0 || qx0,qy0,qx1,qy1, 1,1,1,0),  q = pieces of h' = fl(h - o)
-            int far = 0;
-            for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
-                const int h = (ht0 + (i >> 5)) * 32 + (i & 31);
-                float2 hp = make_float2(0.f, 0.f);
-                if (h < hn) hp = hyp_k[h];
-                far |= !(fabsf(hp.x) < 1e15f && fabsf(hp.y) < 1e15f);
-                __bf16 qx[3], qy[3];
-                split3(hp.x - org.x, qx);
-                split3(hp.y - org.y, qy);
-                const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
-                const bf16x8 lo8 = {qx[0], qy[0], qx[1], qx[2], qx[0], qy[1], qy[2], qy[0]};
-                const bf16x8 hi8 = {qx[0], qy[0], qx[1], qy[1], one, one, one, zero};
-                sB[(i >> 5) * 64 + (i & 31)] = lo8;
-                sB[(i >> 5) * 64 + 32 + (i & 31)] = hi8;
-                sCnt[i] = 0;        // zeroed and (below) flushed by the same thread
+            if (g > g0) {
+                // ---- B operands of the next group (the first group's were staged with the pixels)
+                far = 0;
+                for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
+                    const int h = (ht0 + (i >> 5)) * 32 + (i & 31);
+                    far |= stage_hypothesis(sB, sCnt, i, h < hn ? hyp_k[h] : make_float2(0.f, 0.f), org);
+                }
+                far = __syncthreads_or(far);
             }
-            far = __syncthreads_or(far);
+            PVV_STAMP(6);
 
             if (__builtin_expect(far, 0)) {
                 // some hypothesis of the group is non-finite / astronomically far: exact loop (K:100-125)
@@ -324,12 +399,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                     if (inl) atomicAdd(&sCnt[ht * 32 + col], inl);    // LDS: 2 lanes x 4 waves per hypothesis
                 }
             }
+            PVV_STAMP(7);
             __syncthreads();
             for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
                 const int h = ht0 * 32 + i;
                 const int c = sCnt[i];
                 if (h < hn && c != 0) atomicAdd(&counts[(size_t)bk * hn + h], c);
             }
+            PVV_STAMP(8);
         }
     }
+    PVV_STAMP(9);
+    PVV_CENSUS_OUT(n_items_done);
+    (void)n_items_done;
 }

@@ -71,7 +71,7 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
     int T;
-    size_t tiles, tile_list, tn, coords, dirs, hyps, counts, sums, total;
+    size_t tiles, tile_list, tile_draw, tn, coords, dirs, hyps, counts, sums, total;
 };
 
 Layout make_layout(const pvv_problem *p)
@@ -83,6 +83,7 @@ Layout make_layout(const pvv_problem *p)
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     L.tiles = take(sizeof(uint32_t) * (size_t)p->B * L.T);
     L.tile_list = take(sizeof(unsigned short) * (size_t)p->B * L.T * kTile);
+    L.tile_draw = take(sizeof(float) * (size_t)p->B * L.T * kTile);
     L.tn = take(sizeof(int) * (size_t)p->B);
     L.coords = take(sizeof(float2) * (size_t)p->B * p->cap);
     L.dirs = take(sizeof(float2) * (size_t)p->B * p->K * p->cap);
@@ -187,6 +188,17 @@ int tuning_int(const char *name, int dflt)
 #endif
 }
 
+long long *tuning_ptr(const char *name)
+{
+#ifdef PVV_TUNING
+    const char *e = getenv(name);      // re-read on every call: the tuning scripts change it between calls
+    return e && *e ? (long long *)strtoull(e, nullptr, 0) : nullptr;
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st)
 {
     // persistent blocks per CU (5 are resident): every block builds the item table once, so few blocks are better when
@@ -199,11 +211,14 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     // last chunks of all images up in the same blocks.
     const int per_cu_t = tuning_int("PVV_GRID_PER_CU", 0);
     const int items_per_cu = tuning_int("PVV_ITEMS_PER_CU", 2);
-    const int per_cu = per_cu_t > 0 ? per_cu_t : (p->hn <= 512 ? 15 : 48);
+    // Small batches (every item fits the 5 resident blocks per CU): exactly one generation of blocks -- a block
+    // without an item still costs ~1 us (it has to read tn[] to find that out), and three generations of them kept
+    // the kernel alive 2 us after the last working block at B = 1.
+    const int per_cu = per_cu_t > 0 ? per_cu_t : (p->B <= 8 ? 5 : (p->hn <= 512 ? 15 : 48));
     hipLaunchKernelGGL(k_count_bf16, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, (const float2 *)(ws + L.coords),
                        (const float2 *)(ws + L.dirs), (const float2 *)(ws + L.hyps), (int *)(ws + L.counts),
                        (const int *)(ws + L.tn), p->B, p->K, p->hn, p->cap, p->inlier_thresh,
-                       bf16_consts(p->inlier_thresh), items_per_cu * num_cus());
+                       bf16_consts(p->inlier_thresh), tuning_int("PVV_TARGET_ITEMS", items_per_cu * num_cus()), tuning_ptr("PVV_DBG_PTR"));
     return check_launch("k_count_bf16");
 }
 
@@ -234,18 +249,24 @@ template <int ES>
 void launch_scan(const MaskArgs &m, const Layout &L, char *ws, int B, hipStream_t st)
 {
     hipLaunchKernelGGL(k_tile_scan<ES>, dim3(L.T, B), dim3(kBlock), 0, st, m, (uint32_t *)(ws + L.tiles),
-                       (unsigned short *)(ws + L.tile_list));
+                       (unsigned short *)(ws + L.tile_list), (float *)(ws + L.tile_draw));
 }
 
-// mask scan + (subsample) + compaction and hypotheses + counting, shared by both layers.
+struct Front {
+    MaskArgs m;
+    VertexArgs v;
+    HypArgs h;
+    bool can_subsample;
+};
+
 // stream_first / stream_rest: RNG stream of the hypotheses [0, hn_first) / [hn_first, hn) -- 1 for
 // ransac_voting_layer_v3, 3 for the estimate, so that the two layers never share draws under one seed
-int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d_vertex,
-              const int32_t *d_idxs, const float *d_selection, char *ws, const Layout &L,
-              hipStream_t st, int32_t *d_tn, const float *d_seg = nullptr, int64_t *d_mask_out = nullptr,
-              const int32_t *d_idxs2 = nullptr, int hn_first = -1, uint32_t stream_first = 1u, uint32_t stream_rest = 3u)
+Front make_front(const pvv_problem *p, int mode, const void *d_mask, const float *d_vertex, const int32_t *d_idxs,
+                 const float *d_selection, char *ws, const Layout &L, int32_t *d_tn, const float *d_seg,
+                 int64_t *d_mask_out, const int32_t *d_idxs2, int hn_first, uint32_t stream_first, uint32_t stream_rest)
 {
-    MaskArgs m;
+    Front f;
+    MaskArgs &m = f.m;
     m.mask = d_mask;
     m.seg = d_seg;
     m.mask_out = (long long *)d_mask_out;
@@ -262,34 +283,22 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
     m.b0 = p->first_image;
     m.tn_user = d_tn;
     // Subsampling inside k_compact_hyp (no k_tile_subsample launch) only for images of <= kFuseSubTiles tiles, only when
-    // subsampling is unlikely -- max_num at least 1/16 of the image (30000 of 307200); the reference's default call
-    // (128 hypotheses on max_num = 100 pixels, resnet18.py:75) subsamples EVERY image -- and only with the device RNG:
+    // subsampling is unlikely -- max_num at least 1/16 of the image (30000 of 307200) -- and only with the device RNG:
     // injected index pairs address rows of the SUBSAMPLED list, which the hypothesis blocks can read off the tile lists
     // only after k_tile_subsample has rewritten them.
     m.fuse_sub = (L.T <= kFuseSubTiles && (long long)p->max_num * 16 >= (long long)p->H * p->W && !d_idxs && !d_idxs2) ? 1 : 0;
     // largest possible foreground_num: the sum of byte values (P:126), of class indices (fused argmax) or of ones (P:208)
     const long long max_weight = mode == 1 ? 1 : (d_seg ? (p->seg_classes > 1 ? p->seg_classes - 1 : 1) : 255);
-    const bool can_subsample = (long long)p->max_num < max_weight * (long long)p->H * p->W;
-    VertexArgs v;
+    f.can_subsample = (long long)p->max_num < max_weight * (long long)p->H * p->W;
+    m.want_draws = f.can_subsample ? 1 : 0;
+    VertexArgs &v = f.v;
     v.vertex = d_vertex;
     v.sb = p->vertex_stride[0]; v.sh = p->vertex_stride[1]; v.sw = p->vertex_stride[2];
     v.sk = p->vertex_stride[3]; v.sc = p->vertex_stride[4];
     v.K = p->K;
     v.vec2 = (v.sc == 1 && !(v.sb & 1) && !(v.sh & 1) && !(v.sw & 1) && !(v.sk & 1) &&
               ((uintptr_t)d_vertex % 8 == 0)) ? 1 : 0;
-    switch (m.es) {
-    case 1: launch_scan<1>(m, L, ws, p->B, st); break;
-    case 2: launch_scan<2>(m, L, ws, p->B, st); break;
-    case 4: launch_scan<4>(m, L, ws, p->B, st); break;
-    default: launch_scan<8>(m, L, ws, p->B, st); break;
-    }
-    if (int e = check_launch("k_tile_scan")) return e;
-    if (!m.fuse_sub && can_subsample) {
-        hipLaunchKernelGGL(k_tile_subsample, dim3(L.T, p->B), dim3(kBlock), 0, st, m, (uint32_t *)(ws + L.tiles),
-                           (unsigned short *)(ws + L.tile_list));
-        if (int e = check_launch("k_tile_subsample")) return e;
-    }
-    HypArgs h;
+    HypArgs &h = f.h;
     h.idxs = d_idxs; h.idxs2 = d_idxs2;
     h.hn = p->hn; h.hn_first = hn_first < 0 ? p->hn : hn_first;
     h.stream = stream_first; h.stream2 = stream_rest;
@@ -297,9 +306,38 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
     h.counts = (int *)(ws + L.counts);
     h.draws_out = p->d_draws_out;
     h.blocks = (int)(((long long)p->K * p->hn + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_compact_hyp, dim3(L.T + h.blocks, p->B), dim3(kBlock), sizeof(int) * (size_t)L.T, st, m, v, h,
-                       (const uint32_t *)(ws + L.tiles), (const unsigned short *)(ws + L.tile_list),
-                       (int *)(ws + L.tn), (float2 *)(ws + L.coords), (float2 *)(ws + L.dirs));
+    return f;
+}
+
+int run_scan(const pvv_problem *p, const Front &f, char *ws, const Layout &L, hipStream_t st)
+{
+    switch (f.m.es) {
+    case 1: launch_scan<1>(f.m, L, ws, p->B, st); break;
+    case 2: launch_scan<2>(f.m, L, ws, p->B, st); break;
+    case 4: launch_scan<4>(f.m, L, ws, p->B, st); break;
+    default: launch_scan<8>(f.m, L, ws, p->B, st); break;
+    }
+    return check_launch("k_tile_scan");
+}
+
+// mask scan + (subsample) + compaction and hypotheses + counting, shared by both layers.
+int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d_vertex,
+              const int32_t *d_idxs, const float *d_selection, char *ws, const Layout &L,
+              hipStream_t st, int32_t *d_tn, const float *d_seg = nullptr, int64_t *d_mask_out = nullptr,
+              const int32_t *d_idxs2 = nullptr, int hn_first = -1, uint32_t stream_first = 1u, uint32_t stream_rest = 3u)
+{
+    const Front f = make_front(p, mode, d_mask, d_vertex, d_idxs, d_selection, ws, L, d_tn, d_seg, d_mask_out, d_idxs2,
+                               hn_first, stream_first, stream_rest);
+    if (int e = run_scan(p, f, ws, L, st)) return e;
+    if (!f.m.fuse_sub && f.can_subsample) {
+        hipLaunchKernelGGL(k_tile_subsample, dim3(L.T, p->B), dim3(kBlock), 0, st, f.m, (uint32_t *)(ws + L.tiles),
+                           (unsigned short *)(ws + L.tile_list), (const float *)(ws + L.tile_draw));
+        if (int e = check_launch("k_tile_subsample")) return e;
+    }
+    hipLaunchKernelGGL(k_compact_hyp, dim3(L.T + f.h.blocks, p->B), dim3(kBlock), sizeof(int) * (size_t)L.T, st, f.m, f.v,
+                       f.h, (const uint32_t *)(ws + L.tiles), (const unsigned short *)(ws + L.tile_list),
+                       (const float *)(ws + L.tile_draw), (int *)(ws + L.tn), (float2 *)(ws + L.coords),
+                       (float2 *)(ws + L.dirs));
     if (int e = check_launch("k_compact_hyp")) return e;
     return launch_count_any(p, L, ws, st);
 }
