@@ -15,7 +15,7 @@ _MAX_BATCH = 1024   # images per launch (the count kernel's item table)
 
 
 def decode_keypoint(output, un_pnp=False, *, idxs=None, selection=None, singular="reference", idxs_est=None,
-                    weights=False):
+                    weights=False, seed=None, first_image=0):
     """In-place update of ``output`` exactly like the reference method: adds ``mask`` [b,h,w] int64, ``kpt_2d``
     [b,vn,2] and -- with ``un_pnp`` (``cfg.test.un_pnp``, config.py:75) -- ``var`` [b,vn,2,2].
 
@@ -28,30 +28,52 @@ def decode_keypoint(output, un_pnp=False, *, idxs=None, selection=None, singular
     on the same draws; ``idxs_est`` [b,4096,vn,2] injects the estimate's index pairs like ``idxs`` does for v3, and
     ``weights=True`` also stores ``var_weights`` [b,vn,3] = (wxx,wxy,wyy) of ``inv(sqrtm(var))``, what the evaluator
     feeds uncertainty_pnp (evaluators/linemod/pvnet.py:118-130).
+
+    ``seed`` / ``first_image`` key the device RNG exactly as in the layers (``ransac_voting_gpu``): batches beyond 1024
+    images are cut into several launches here, and a batch sharded over GPUs decodes to the same result as one call
+    when every shard passes the common ``seed`` and the index of its first image.
     """
     seg = output["seg"]
     ver = output["vertex"]
     b, vn_2, h, w = ver.shape
     vertex = ver.permute(0, 2, 3, 1).view(b, h, w, vn_2 // 2, 2)              # resnet18.py:66-68, a strided view
-    if un_pnp and seg.shape[1] == 2 and b <= _MAX_BATCH:
-        # resnet18.py:71-72 fused; the estimate's defaults (P:202): ceil(4096 / 256) rounds of 256 hypotheses
-        kpt, mask, var, w, _win, _tn = _ext.decode_keypoint_un_pnp(seg.float(), vertex, 512, 4096, 0.99, 5, 30000, idxs,
-                                                                   idxs_est, selection, _next_seed(), _POLICY[singular])
-        output.update({"mask": mask, "kpt_2d": kpt, "var": var})
-        if weights:
-            output["var_weights"] = w
-        return output
+    seed = _next_seed() if seed is None else int(seed)
+    segf = seg.float()
+    fused = un_pnp and seg.shape[1] == 2
     if un_pnp:
         hn, max_num = 512, 30000                                             # resnet18.py:71
     else:
         hn, max_num = 128, 100                                               # resnet18.py:75
-    kpt, mask, _win, _tn = _ext.decode_keypoint_v3(seg.float(), vertex, hn, 0.99, 5, max_num, idxs, selection,
-                                                   _next_seed(), _POLICY[singular])
+    parts = {"mask": [], "kpt_2d": [], "var": [], "var_weights": []}
+    for lo in range(0, max(b, 1), _MAX_BATCH) if b else []:
+        hi = min(b, lo + _MAX_BATCH)
+        sl = slice(lo, hi)
+        cut = lambda t: None if t is None else t[sl]                          # noqa: E731
+        first = int(first_image) + lo
+        if fused:
+            # resnet18.py:71-72 fused; the estimate's defaults (P:202): ceil(4096 / 256) rounds of 256 hypotheses
+            kpt, mask, var, wts, _win, _tn = _ext.decode_keypoint_un_pnp(segf[sl], vertex[sl], 512, 4096, 0.99, 5, 30000,
+                                                                         cut(idxs), cut(idxs_est), cut(selection), seed,
+                                                                         _POLICY[singular], first)
+        else:
+            kpt, mask, _win, _tn = _ext.decode_keypoint_v3(segf[sl], vertex[sl], hn, 0.99, 5, max_num, cut(idxs),
+                                                           cut(selection), seed, _POLICY[singular], first)
+            var = wts = None
+            if un_pnp:                                                        # resnet18.py:72
+                res = estimate_voting_distribution_with_mean(mask, vertex[sl], kpt, idxs=cut(idxs_est), return_weights=weights,
+                                                             seed=seed, first_image=first)
+                kpt, var = res[0], res[1]
+                wts = res[2] if weights else None
+        for k, t in (("mask", mask), ("kpt_2d", kpt), ("var", var), ("var_weights", wts)):
+            if t is not None:
+                parts[k].append(t)
+    if b == 0:
+        parts = {"mask": [seg.new_zeros((0, h, w), dtype=torch.int64)], "kpt_2d": [ver.new_zeros((0, vn_2 // 2, 2))],
+                 "var": [ver.new_zeros((0, vn_2 // 2, 2, 2))], "var_weights": [ver.new_zeros((0, vn_2 // 2, 3))]}
+    cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts)                 # noqa: E731
+    output.update({"mask": cat(parts["mask"]), "kpt_2d": cat(parts["kpt_2d"])})
     if un_pnp:
-        res = estimate_voting_distribution_with_mean(mask, vertex, kpt, idxs=idxs_est, return_weights=weights)   # resnet18.py:72
-        output.update({"mask": mask, "kpt_2d": res[0], "var": res[1]})
+        output["var"] = cat(parts["var"])
         if weights:
-            output["var_weights"] = res[2]
-    else:
-        output.update({"mask": mask, "kpt_2d": kpt})
+            output["var_weights"] = cat(parts["var_weights"])
     return output

@@ -41,19 +41,21 @@ def _worker(rank, world, port, batch, q):
             idxs = synth.make_idxs(tn, hn, vertex.shape[3], first_index=lo).numpy()
             return torch.from_numpy(vote_oracle.ransac_voting_layer_v3(mask.numpy(), vertex.numpy(), hn, 0.99, idxs=idxs))
 
-        if d is not None:
-            out = pdist.sharded_vote(vote, d["mask"], d["vertex"], batch, cfg["hn"])
-            # seed= : every rank votes with the common key and the index of ITS first image (device-RNG results are
-            # then independent of the sharding)
-            seen = {}
+        # a rank without images (batch < world, or the tail of an uneven split) makes the same calls with zero rows:
+        # sharded_vote itself must enter the collective -- ADVICE r1: it used to call the layer on an empty batch and
+        # hang the others
+        m = d["mask"] if d is not None else torch.zeros(0, cfg["H"], cfg["W"], dtype=torch.int64)
+        v = d["vertex"] if d is not None else torch.zeros(0, cfg["H"], cfg["W"], cfg["K"], 2)
+        out = pdist.sharded_vote(vote, m, v, batch, cfg["hn"])
+        # seed= : every rank votes with the common key and the index of ITS first image (device-RNG results are
+        # then independent of the sharding)
+        seen = {}
 
-            def vote_kw(mask, vertex, hn, **kw):
-                seen.update(kw)
-                return vote(mask, vertex, hn)
-            out_s = pdist.sharded_vote(vote_kw, d["mask"], d["vertex"], batch, cfg["hn"], seed=777)
-            assert seen == {"seed": 777, "first_image": lo} and torch.equal(out_s, out)
-        else:
-            out = pdist.gather_results(torch.zeros(0, cfg["K"], 2), batch)
+        def vote_kw(mask, vertex, hn, **kw):
+            seen.update(kw)
+            return vote(mask, vertex, hn)
+        out_s = pdist.sharded_vote(vote_kw, m, v, batch, cfg["hn"], seed=777)
+        assert torch.equal(out_s, out) and (d is None or seen == {"seed": 777, "first_image": lo})
         cov_local = torch.arange((hi - lo) * cfg["K"] * 4, dtype=torch.float32).view(hi - lo, cfg["K"], 2, 2) + 1000 * rank
         cov = pdist.gather_results(cov_local, batch)
         # async form (what bench.py uses to overlap the exchange with the next batch's voting)
@@ -65,9 +67,8 @@ def _worker(rank, world, port, batch, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("batch", [4, 5])
-def test_two_rank_gloo_sharded_vote_equals_single_process(oracle, synth, batch):
-    world = 2
+@pytest.mark.parametrize("batch,world", [(4, 2), (5, 2), (2, 3)])
+def test_gloo_sharded_vote_equals_single_process(oracle, synth, batch, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -88,4 +89,4 @@ def test_two_rank_gloo_sharded_vote_equals_single_process(oracle, synth, batch):
         assert out.shape == (batch, cfg["K"], 2)
         np.testing.assert_array_equal(out, want)                                    # every rank holds the full result
         per = -(-batch // world)
-        assert cov.shape == (batch, cfg["K"], 2, 2) and cov[0, 0, 0, 0] == 0 and cov[per, 0, 0, 0] == 1000
+        assert cov.shape == (batch, cfg["K"], 2, 2) and cov[0, 0, 0, 0] == 0 and (per >= batch or cov[per, 0, 0, 0] == 1000)

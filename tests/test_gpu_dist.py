@@ -1,0 +1,77 @@
+"""The N > 1 path on the GPU box, as far as one GPU can show it: a real RCCL ("nccl") process group of ONE rank --
+``bench.py`` launched the way the driver launches it for N > 1 (torch.distributed.run), and the HIP layer under
+``clean_pvnet_amd.dist.sharded_vote`` compared with the un-sharded call.  (Two and more ranks: tests/test_dist.py on gloo.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _env():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    return env
+
+
+def test_bench_under_torchrun_one_rank_executes_the_rccl_exchange(gpu):
+    """python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1: init_process_group("nccl"), an
+    all_gather_into_tensor in EVERY step, barrier + max-over-ranks timing -- the N > 1 code path, one rank."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+           "--batch", "4", "--rotate", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=_env(), timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["scaling"] == "strong"
+    assert line["extra"]["rccl_ranks"] == 1 and "all_gather_into_tensor" in line["extra"]["exchange"]
+    assert line["config"]["global_batch"] == 4 and line["config"]["batch_per_gpu"] == 4
+    assert line["value"] > 0 and line["extra"]["known_answer_max_err_px"] < 20
+    assert len(line["extra"]["per_rank_count_kernel_ms"]) == 1 and line["roofline"]["kernel_ms_avg"] > 0
+
+
+_SHARDED = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import lib; lib._register_clean_pvnet_amd()
+from clean_pvnet_amd import dist as pdist, synth
+from lib.csrc.ransac_voting.ransac_voting_gpu import ransac_voting_layer_v3, estimate_voting_distribution_with_mean
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+c = {**synth.CONFIGS["cfg1"], "B": 5}
+d = synth.make_batch(**c, device=dev)
+lo, hi = pdist.shard_bounds(5, dist.get_world_size(), dist.get_rank())
+assert (lo, hi) == (0, 5)
+got = pdist.sharded_vote(ransac_voting_layer_v3, d["mask"][lo:hi], d["vertex"][lo:hi], 5, c["hn"], inlier_thresh=0.99, seed=4242)
+want = ransac_voting_layer_v3(d["mask"], d["vertex"], c["hn"], inlier_thresh=0.99, seed=4242)
+# the shard split in two calls, as two ranks would make them, through the same collective
+a = ransac_voting_layer_v3(d["mask"][:3], d["vertex"][:3], c["hn"], inlier_thresh=0.99, seed=4242, first_image=0)
+b = ransac_voting_layer_v3(d["mask"][3:], d["vertex"][3:], c["hn"], inlier_thresh=0.99, seed=4242, first_image=3)
+both = pdist.gather_results(torch.cat([a, b]), 5)
+# an empty shard enters the collective too (a trailing rank of an uneven split)
+empty = pdist.sharded_vote(ransac_voting_layer_v3, d["mask"][:0], d["vertex"][:0], 0, c["hn"], inlier_thresh=0.99, seed=1)
+mean, cov = estimate_voting_distribution_with_mean(d["mask"], d["vertex"], want, seed=7)
+cov_g = pdist.gather_results(cov, 5)
+torch.cuda.synchronize()
+print(json.dumps(dict(equal=bool(torch.equal(got, want)), split_equal=bool(torch.equal(both, want)), shape=list(got.shape),
+                      empty=list(empty.shape), cov_equal=bool(torch.equal(cov_g, cov)), backend=dist.get_backend(),
+                      err=float((got - d["kpt_2d"]).abs().max()))))
+dist.destroy_process_group()
+""" % ROOT
+
+
+def test_hip_layer_under_a_one_rank_nccl_group_equals_the_unsharded_call(gpu):
+    env = dict(_env(), MASTER_PORT="29534")
+    r = subprocess.run([sys.executable, "-c", _SHARDED], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, "no result line:\n%s\n%s" % (r.stdout[-2000:], r.stderr[-2000:])
+    res = json.loads(lines[-1])
+    assert res["backend"] == "nccl"
+    assert res["equal"] and res["split_equal"] and res["cov_equal"]
+    assert res["shape"] == [5, 4, 2] and res["empty"] == [0, 4, 2] and res["err"] < 10

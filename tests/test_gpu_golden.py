@@ -1,10 +1,13 @@
 """GPU: the HIP path against the committed golden fixtures produced by the reference's own Python glue
-(tests/golden/make_golden.py).  Same tolerances as tests/test_oracle.py uses for the oracle."""
+(tests/golden/make_golden.py).  Tolerance: tests/tolerances.py -- 1e-4 abs + 2e-6 rel, plus the reference's OWN measured
+deviation from the exact (rational) least-squares solution of the same inlier set (its binary32 accumulation)."""
 import os
 
 import numpy as np
 import pytest
 import torch
+
+from tests import tolerances as tol
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -16,34 +19,43 @@ def gold(name, gpu):
     return c, t
 
 
-def test_v3_basic(pkg, gpu):
+def test_v3_basic(oracle, pkg, gpu):
     from clean_pvnet_amd.ransac_voting_gpu import ransac_voting_layer_v3
     c, t = gold("v3_basic", gpu)
     out = ransac_voting_layer_v3(t["mask"], t["vertex"], int(c["hn"]), inlier_thresh=float(c["thresh"]), idxs=t["idxs"])
-    np.testing.assert_allclose(out.cpu().numpy(), c["out"], rtol=0, atol=2e-4)
+    exact = tol.exact_v3(oracle, c["mask"], c["vertex"], int(c["hn"]), float(c["thresh"]), c["idxs"])
+    tol.assert_means_close(out.cpu().numpy(), exact)                                   # within the contract of the exact answer
+    tol.assert_means_close(out.cpu().numpy(), c["out"], extra=np.abs(c["out"] - exact))
     assert (out[2] == 0).all()
 
 
-def test_v3_subsample(pkg, gpu):
+def test_v3_subsample(oracle, pkg, gpu):
     from clean_pvnet_amd.ransac_voting_gpu import ransac_voting_layer_v3
     c, t = gold("v3_subsample", gpu)
     out = ransac_voting_layer_v3(t["mask"], t["vertex"], int(c["hn"]), inlier_thresh=float(c["thresh"]),
                                  max_num=int(c["max_num"]), idxs=t["idxs"], selection=t["selection"])
-    np.testing.assert_allclose(out.cpu().numpy(), c["out"], rtol=0, atol=5e-4)
+    exact = tol.exact_v3(oracle, c["mask"], c["vertex"], int(c["hn"]), float(c["thresh"]), c["idxs"], selection=c["selection"],
+                         max_num=int(c["max_num"]))
+    tol.assert_means_close(out.cpu().numpy(), exact)
+    tol.assert_means_close(out.cpu().numpy(), c["out"], extra=np.abs(c["out"] - exact))
+    assert np.abs(c["out"] - exact).max() > 1e-4        # the fixture where the reference's own rounding exceeds the contract
 
 
-def test_v3_singular_reference_policy_is_default(pkg, gpu):
+def test_v3_singular_reference_policy_is_default(oracle, pkg, gpu):
     from clean_pvnet_amd.ransac_voting_gpu import ransac_voting_layer_v3
     c, t = gold("v3_singular", gpu)
     out = ransac_voting_layer_v3(t["mask"], t["vertex"], int(c["hn"]), inlier_thresh=float(c["thresh"]), idxs=t["idxs"])
-    np.testing.assert_allclose(out.cpu().numpy(), c["out"], rtol=2e-6, atol=1e-3)
+    exact = tol.exact_v3(oracle, c["mask"], c["vertex"], int(c["hn"]), float(c["thresh"]), c["idxs"])
+    tol.assert_means_close(out.cpu().numpy(), exact)
+    tol.assert_means_close(out.cpu().numpy(), c["out"], extra=np.abs(c["out"] - exact))
 
 
-def test_v1_layer(pkg, gpu):
+def test_v1_layer(oracle, pkg, gpu):
     from clean_pvnet_amd.ransac_voting_gpu import ransac_voting_layer
     c, t = gold("v1_basic", gpu)
     out = ransac_voting_layer(t["mask"], t["vertex"], int(c["hn"]), inlier_thresh=float(c["thresh"]), idxs=t["idxs"])
-    np.testing.assert_allclose(out.cpu().numpy(), c["out"], rtol=0, atol=2e-4)
+    exact = tol.exact_v3(oracle, c["mask"], c["vertex"], int(c["hn"]), float(c["thresh"]), c["idxs"], singular="zero")
+    tol.assert_means_close(out.cpu().numpy(), c["out"], extra=np.abs(c["out"] - exact))
 
 
 def test_estimate(pkg, gpu):
@@ -51,5 +63,5 @@ def test_estimate(pkg, gpu):
     c, t = gold("estimate_basic", gpu)
     mean, cov = estimate_voting_distribution_with_mean(t["mask"], t["vertex"], t["mean"], int(c["round_hyp_num"]),
                                                        int(c["min_hyp_num"]), idxs=t["idxs"])
-    np.testing.assert_allclose(cov.cpu().numpy(), c["cov"], rtol=2e-5, atol=1e-4)
+    tol.assert_cov_close(cov.cpu().numpy(), c["cov"], rtol=tol.COV_RTOL_VS_REFERENCE_F32, what="cov vs the reference's float32 glue")
     assert mean is t["mean"]

@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from tests import capi
+from tests import tolerances as tol
 
 pytestmark = pytest.mark.gpu
 
@@ -191,7 +192,7 @@ def _check_v3(oracle, got_out, got_win, got_tn, mask, vertex, idxs, hn, thresh, 
                          for r in details])
     np.testing.assert_array_equal(_np(got_tn), want_tn)
     np.testing.assert_array_equal(_np(got_win), want_win)          # inlier counts: bit-exact
-    np.testing.assert_allclose(_np(got_out), want, rtol=0, atol=ATOL)
+    tol.assert_means_close(_np(got_out), want)
     return want, details
 
 
@@ -286,14 +287,14 @@ def test_v3_singular_keypoint_policies(oracle, synth, pkg, gpu, singular):
     want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, 0.99, idxs=_np(idxs), singular=singular, details=det)
     assert det[0]["singular"][1] == 1 and det[0]["win_counts"][1] == 0
     if singular == "reference":
-        np.testing.assert_allclose(_np(got), want, rtol=1e-6, atol=ATOL)       # ATb is huge: relative
+        tol.assert_means_close(_np(got), want)       # ATb is huge: relative
         assert np.abs(want[0]).max() > 1e3
     else:
-        np.testing.assert_allclose(_np(got), want, rtol=0, atol=ATOL)
+        tol.assert_means_close(_np(got), want)
         assert (want[0, 1] == 0).all() and np.abs(want[0, 0] - _np(d["kpt_2d"])[0, 0]).max() < 2
     v1 = ransac_voting_layer(m, v, hn, inlier_thresh=0.99, idxs=i)             # v1: whole image zeros
     assert (_np(v1)[0] == 0).all()
-    np.testing.assert_allclose(_np(v1)[1], want[1], rtol=0, atol=ATOL)
+    tol.assert_means_close(_np(v1)[1], want[1])
 
 
 def test_v3_subsample_with_injected_selection(oracle, synth, pkg, gpu):
@@ -365,7 +366,7 @@ def test_estimate_parity(oracle, synth, pkg, gpu, cfg, B, round_hyp, min_hyp):
     ret_mean, cov, hyp, ratio = estimate_voting_distribution_with_mean(m, v, mu, round_hyp, min_hyp, idxs=i,
                                                                       output_hyp=True)
     assert ret_mean is mu and cov.shape == (B, c["K"], 2, 2)
-    np.testing.assert_allclose(_np(cov), want, rtol=1e-4, atol=ATOL)
+    tol.assert_cov_close(_np(cov), want)
     r0 = det[0]
     np.testing.assert_array_equal(_np(hyp[0]).view(np.uint32), r0["hypo_pts"].transpose(1, 0, 2).view(np.uint32))
     want_ratio = (r0["counts"].astype(np.float32) / np.float32(r0["tn"])).T
@@ -381,7 +382,7 @@ def test_estimate_parity(oracle, synth, pkg, gpu, cfg, B, round_hyp, min_hyp):
 # full-size, size-independent properties (BASELINE configs 3-5)
 # --------------------------------------------------------------------------------------------------
 def test_full_size_cfg3_properties_and_sampled_oracle(oracle, synth, pkg, gpu):
-    """B=64, 480x640, K=9, 512 hypotheses on one GPU: (i) three sampled images against the oracle,
+    """B=64, 480x640, K=9, 512 hypotheses on one GPU: (i) EVERY image against the oracle (winner counts, means),
     (ii) permuting the batch permutes the result, (iii) run-to-run determinism, (iv) fused counts ==
     legacy vote + sum for one image."""
     from clean_pvnet_amd import ransac_voting as ext
@@ -393,12 +394,12 @@ def test_full_size_cfg3_properties_and_sampled_oracle(oracle, synth, pkg, gpu):
     out, win, tnn, _ws = ext.ransac_voting_v3(mask, vertex, c["hn"], 0.99, 5, 30000, idxs, None, 0, ext.SINGULAR_REFERENCE)
     assert _np(tnn).tolist() == tn
     assert np.abs(_np(out) - _np(d["kpt_2d"])).max() < 6.0
-    for bi in (0, 31, 63):
+    for bi in range(c["B"]):
         det = []
         want = oracle.ransac_voting_layer_v3(_np(mask[bi:bi + 1]), _np(vertex[bi:bi + 1]), c["hn"], 0.99,
                                              idxs=_np(idxs[bi:bi + 1]), details=det)
         np.testing.assert_array_equal(_np(win[bi]), det[0]["win_counts"])
-        np.testing.assert_allclose(_np(out[bi:bi + 1]), want, rtol=0, atol=ATOL)
+        tol.assert_means_close(_np(out[bi:bi + 1]), want)
     perm = torch.randperm(c["B"], generator=torch.Generator().manual_seed(1)).to(gpu)
     out_p, win_p, _t, _w = ext.ransac_voting_v3(mask[perm], vertex[perm], c["hn"], 0.99, 5, 30000, idxs[perm], None, 0,
                                                 ext.SINGULAR_REFERENCE)
@@ -409,9 +410,11 @@ def test_full_size_cfg3_properties_and_sampled_oracle(oracle, synth, pkg, gpu):
 
 
 @pytest.mark.parametrize("cfg,B", [("cfg4", 4), ("cfg5", 2)])
-def test_stress_configs_sampled_oracle(oracle, synth, pkg, gpu, cfg, B):
+def test_stress_configs_every_image_all_counts(oracle, synth, pkg, gpu, cfg, B):
     """cfg4 (sparse/occluded, 1024 hyps, outlier pixels) and cfg5 (540x720, K=17, 2048 hyps, tn capped by
-    max_num=30000 -> subsampling with injected draws) at reduced batch, full image size."""
+    max_num=30000 -> subsampling with injected draws) at reduced batch, full image size: EVERY image's tn, winner
+    counts and means against the oracle, and all K*hn inlier counts (through the estimate entry of the C ABI, whose
+    foreground `mask == 1` coincides with v3's on these 0/1 masks)."""
     from clean_pvnet_amd import ransac_voting as ext
     c = {**synth.CONFIGS[cfg], "B": B}
     d = synth.make_batch(**c, seed=4321)
@@ -426,7 +429,143 @@ def test_stress_configs_sampled_oracle(oracle, synth, pkg, gpu, cfg, B):
     out, win, tnn, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), c["hn"], 0.99, 5, 30000, idxs.to(gpu),
                                               selection.to(gpu), 0, ext.SINGULAR_REFERENCE)
     assert _np(tnn).tolist() == tn
-    _check_v3(oracle, out[:1], win[:1], tnn[:1], mask[:1], vertex[:1], idxs[:1], c["hn"], 0.99, selection=selection[:1])
+    _want, det = _check_v3(oracle, out, win, tnn, mask, vertex, idxs, c["hn"], 0.99, selection=selection)
+    cov, hyp, counts, tn2 = capi.estimate(mask.to(gpu), vertex.to(gpu), out, c["hn"], 0.99, idxs=idxs.to(gpu),
+                                          selection=selection.to(gpu))
+    assert _np(tn2).tolist() == tn
+    for bi in range(B):
+        np.testing.assert_array_equal(_np(counts[bi]), det[bi]["counts"].T)          # all K*hn counts, bit-exact
+        np.testing.assert_array_equal(_np(hyp[bi]), det[bi]["hypo_pts"].transpose(1, 0, 2))
+
+
+@pytest.mark.parametrize("planar", [False, True])
+def test_estimate_and_un_pnp_at_480x640_with_4096_hypotheses(oracle, synth, pkg, gpu, planar):
+    """The un_pnp path at the size the network runs it (resnet18.py:71-72): 480x640, K=9, B=4, v3 with 512 hypotheses
+    and the estimate with 16 x 256 = 4096, injected index pairs -- every count, the covariances, and the fused
+    decode_keypoint(un_pnp=True) pass against the oracle."""
+    from clean_pvnet_amd.decode import decode_keypoint
+    from clean_pvnet_amd.ransac_voting_gpu import estimate_voting_distribution_with_mean, ransac_voting_layer_v3
+    B, K, hn, hn_est = 4, 9, 512, 4096
+    c = {**synth.CONFIGS["cfg2"], "B": B}
+    d = synth.make_batch(**c, seed=555, planar=planar)
+    mask, vertex = d["mask"], d["vertex"]
+    tn = [int(x) for x in (mask == 1).sum((1, 2))]
+    idxs = synth.make_idxs(tn, hn, K, seed=555)
+    idxs_est = synth.make_idxs(tn, hn_est, K, seed=556)
+    m, v = mask.to(gpu), vertex.to(gpu)
+    mean = ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, idxs=idxs.to(gpu))
+    want_mean = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, 0.99, idxs=_np(idxs))
+    tol.assert_means_close(_np(mean), want_mean)
+    _mm, cov, hyp, ratio = estimate_voting_distribution_with_mean(m, v, mean, idxs=idxs_est.to(gpu), output_hyp=True)
+    det = []
+    _m2, want_cov = oracle.estimate_voting_distribution_with_mean(_np(mask), _np(vertex), _np(mean), idxs=_np(idxs_est), details=det)
+    tol.assert_cov_close(_np(cov), want_cov)                         # same mean on both sides
+    for bi in range(B):
+        want_ratio = (det[bi]["counts"].astype(np.float32) / np.float32(det[bi]["tn"])).T
+        np.testing.assert_array_equal(_np(ratio[bi]), want_ratio)    # all 4096 x 9 counts of every image
+        np.testing.assert_array_equal(_np(hyp[bi]), det[bi]["hypo_pts"].transpose(1, 0, 2))
+    # the same through Resnet18.decode_keypoint's mirror, one fused pass (two-class seg built around the mask)
+    H, W = c["H"], c["W"]
+    x = torch.empty(B, 2 + 2 * K, H, W)
+    x[:, 0] = 1.0
+    x[:, 1] = torch.where(mask != 0, torch.tensor(4.0), torch.tensor(-4.0))
+    x[:, 2:] = vertex.permute(0, 3, 4, 1, 2).reshape(B, 2 * K, H, W)
+    x = x.to(gpu)
+    o = decode_keypoint({"seg": x[:, :2], "vertex": x[:, 2:]}, un_pnp=True, idxs=idxs.to(gpu), idxs_est=idxs_est.to(gpu))
+    assert torch.equal(o["mask"], m)
+    np.testing.assert_array_equal(_np(o["kpt_2d"]), _np(mean))       # same kernels, same draws: bit-identical
+    np.testing.assert_array_equal(_np(o["var"]), _np(cov))
+
+
+def test_decode_keypoint_beyond_1024_images_and_sharding_invariance(synth, pkg, gpu):
+    """decode_keypoint cuts batches beyond 1024 images into several launches (it used to raise), and -- given
+    seed= / first_image= -- a batch decoded in shards equals the batch decoded at once (device RNG)."""
+    from clean_pvnet_amd.decode import decode_keypoint
+    B, H, W, K = 1030, 24, 32, 3
+    d = synth.make_batch(B=8, H=H, W=W, K=K, fg=0.3, sigma=0.03, seed=77, planar=True)
+    rep = (B + 7) // 8
+    mask = d["mask"].repeat(rep, 1, 1)[:B]
+    vertex_store = d["vertex"].permute(0, 3, 4, 1, 2).reshape(8, 2 * K, H, W).repeat(rep, 1, 1, 1)[:B]
+    x = torch.empty(B, 2 + 2 * K, H, W)
+    x[:, 0] = 1.0
+    x[:, 1] = torch.where(mask != 0, torch.tensor(4.0), torch.tensor(-4.0))
+    x[:, 2:] = vertex_store
+    x = x.to(gpu)
+    for un_pnp in (False, True):
+        whole = decode_keypoint({"seg": x[:, :2], "vertex": x[:, 2:]}, un_pnp=un_pnp, seed=99)
+        assert whole["kpt_2d"].shape == (B, K, 2) and whole["mask"].shape == (B, H, W)
+        a = decode_keypoint({"seg": x[:500, :2], "vertex": x[:500, 2:]}, un_pnp=un_pnp, seed=99, first_image=0)
+        b = decode_keypoint({"seg": x[500:, :2], "vertex": x[500:, 2:]}, un_pnp=un_pnp, seed=99, first_image=500)
+        assert torch.equal(torch.cat([a["kpt_2d"], b["kpt_2d"]]), whole["kpt_2d"])
+        assert torch.equal(torch.cat([a["mask"], b["mask"]]), whole["mask"])
+        if un_pnp:
+            assert whole["var"].shape == (B, K, 2, 2)
+            assert torch.equal(torch.cat([a["var"], b["var"]]), whole["var"])
+        assert float((whole["kpt_2d"][:8].cpu() - d["kpt_2d"]).abs().max()) < 4.0
+
+
+@pytest.mark.parametrize("max_num", [30000, 5000, 2000])
+def test_device_rng_draws_replayed_through_the_oracle(oracle, synth, pkg, gpu, max_num):
+    """The hypothesis blocks of k_compact_hyp with the DEVICE RNG (no injected index pairs -- the path production
+    runs): pvv_problem.d_draws_out reports the pixel every draw resolved to; mapping those pixels to rows of the
+    oracle's compacted list and injecting them reproduces hypotheses, all counts and means exactly.  max_num = 5000
+    subsamples inside k_compact_hyp (max_num >= 1/16 of the image: the index pairs then come from rejection sampling over
+    the survivors), max_num = 2000 through k_tile_subsample (the lists are rewritten first)."""
+    import ctypes
+    c = {**synth.CONFIGS["cfg2"], "B": 2, "H": 240, "W": 320, "fg": 0.12}
+    d = synth.make_batch(**c, seed=31)
+    mask, vertex = d["mask"].to(gpu), d["vertex"].to(gpu)
+    B, H, W, K, hn = 2, 240, 320, c["K"], 256
+    sel = torch.rand(B, H, W, generator=torch.Generator().manual_seed(5))          # injected: the oracle needs the same draws
+    L = capi.load()
+    draws = torch.full((B, K, hn, 2), -7, dtype=torch.int32, device=gpu)
+    p = capi.problem(mask, vertex, hn, 0.99, max_num=max_num, seed=2024, draws_out=draws, cap=H * W)
+    n = L.pvv_workspace_bytes(ctypes.byref(p))
+    ws = torch.empty(n, dtype=torch.uint8, device=gpu)
+    out = torch.empty(B, K, 2, device=gpu)
+    win = torch.empty(B, K, dtype=torch.int32, device=gpu)
+    tn = torch.empty(B, dtype=torch.int32, device=gpu)
+    capi.check(L.pvv_ransac_voting_v3(ctypes.byref(p), capi.ptr(mask), capi.ptr(vertex), None, capi.ptr(sel.to(gpu)), capi.ptr(ws), n,
+                                      capi.ptr(out), capi.ptr(win), capi.ptr(tn), capi.stream()))
+    torch.cuda.synchronize()
+    dr = _np(draws)
+    assert (dr >= 0).all()
+    # pixel -> row of the oracle's compacted (and subsampled) list
+    idxs = np.zeros((B, hn, K, 2), np.int32)
+    for bi in range(B):
+        fg, coords, direct = oracle.compact_v3(_np(mask[bi]), _np(vertex[bi]), max_num, _np(sel[bi]))
+        assert coords.shape[0] == int(tn[bi]) and (fg > max_num) == (max_num < 30000)
+        row = -np.ones(H * W, np.int64)
+        row[(coords[:, 1] * W + coords[:, 0]).astype(np.int64)] = np.arange(coords.shape[0])
+        r = row[dr[bi]]                                            # [K,hn,2]
+        assert (r >= 0).all(), "a draw resolved to a pixel that did not survive the subsample"
+        idxs[bi] = r.transpose(1, 0, 2)
+        # the draws are spread over the whole list (uniform index pairs, not stuck on a tile)
+        assert len(np.unique(r)) > 0.5 * min(coords.shape[0], hn * K)
+    _check_v3(oracle, out, win, tn, mask, vertex, torch.from_numpy(idxs), hn, 0.99, selection=sel, max_num=max_num)
+
+
+def test_fused_un_pnp_equals_the_two_calls_under_one_seed(synth, pkg, gpu):
+    """Device RNG: the v3 layer and the estimate draw from different streams of one seed (they used to share
+    their first draws), and the fused un_pnp pass draws exactly what the two calls draw."""
+    from clean_pvnet_amd import ransac_voting as ext
+    B, H, W, K, hn, hn_est = 3, 96, 128, 5, 64, 160
+    d = synth.make_batch(B=B, H=H, W=W, K=K, fg=0.08, sigma=0.05, seed=91, planar=True)
+    x = torch.empty(B, 2 + 2 * K, H, W)
+    x[:, 0] = 1.0
+    x[:, 1] = torch.where(d["mask"] != 0, torch.tensor(4.0), torch.tensor(-4.0))
+    x[:, 2:] = d["vertex"].permute(0, 3, 4, 1, 2).reshape(B, 2 * K, H, W)
+    x = x.to(gpu)
+    seg, vertex = x[:, :2], x[:, 2:].permute(0, 2, 3, 1).view(B, H, W, K, 2)
+    kpt2, mask2, win2, tn2 = ext.decode_keypoint_v3(seg, vertex, hn, 0.99, 5, 30000, None, None, 4711, ext.SINGULAR_REFERENCE)
+    cov2, hyp2, _c, _t, w2 = ext.estimate_voting_distribution(mask2, vertex, kpt2, hn_est, 0.99, 5, 30000, None, None, 4711, True)
+    kpt, mask, cov, w, win, tnn = ext.decode_keypoint_un_pnp(seg, vertex, hn, hn_est, 0.99, 5, 30000, None, None, None, 4711,
+                                                             ext.SINGULAR_REFERENCE)
+    for a, b in ((mask, mask2), (kpt, kpt2), (cov, cov2), (w, w2), (win, win2), (tnn, tn2)):
+        assert torch.equal(a, b)
+    # counter-based generator: a longer run of the estimate extends a shorter one
+    _cv, hyp_s, _cc, _tt, _ww = ext.estimate_voting_distribution(mask2, vertex, kpt2, hn, 0.99, 5, 30000, None, None, 4711, True)
+    assert torch.equal(hyp_s, hyp2[:, :, :hn])
 
 
 # --------------------------------------------------------------------------------------------------
@@ -452,7 +591,7 @@ def test_v3_parity_shapes_and_thresholds(oracle, synth, pkg, gpu, K, hn, thresh)
     det = []
     want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, thresh, idxs=_np(idxs), details=det, singular="zero")
     np.testing.assert_array_equal(_np(win), np.stack([r["win_counts"] for r in det]))
-    np.testing.assert_allclose(_np(out), want, rtol=0, atol=ATOL)
+    tol.assert_means_close(_np(out), want)
     # every one of the hn*K counts, not just the winners
     m, v = mask.to(gpu), vertex.to(gpu)
     mean = torch.zeros(2, K, 2, device=gpu)
@@ -523,7 +662,7 @@ def test_estimate_subsample_and_multiclass(oracle, synth, pkg, gpu):
                                                              idxs=_np(idxs), selection=_np(selection))
     _m2, cov = estimate_voting_distribution_with_mean(mask.to(gpu), vertex.to(gpu), mean.to(gpu), 64, 128, max_num=max_num,
                                                       idxs=idxs.to(gpu), selection=selection.to(gpu))
-    np.testing.assert_allclose(_np(cov), want, rtol=1e-4, atol=ATOL)
+    tol.assert_cov_close(_np(cov), want)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -564,7 +703,7 @@ def test_decode_keypoint_fused_argmax_equals_unfused(oracle, synth, pkg, gpu, C)
     np.testing.assert_array_equal(_np(win), _np(win_ref))
     np.testing.assert_array_equal(_np(out), _np(out_ref))           # same kernels downstream: bit-identical
     want = oracle.ransac_voting_layer_v3(_np(mask_ref), _np(vertex), hn, 0.99, idxs=_np(idxs))
-    np.testing.assert_allclose(_np(out), want, rtol=0, atol=ATOL)
+    tol.assert_means_close(_np(out), want)
     # the dict-updating mirror of the reference method, both branches
     o = decode_keypoint({"seg": seg, "vertex": ver}, un_pnp=False)
     assert set(o) == {"seg", "vertex", "mask", "kpt_2d"} and o["kpt_2d"].shape == (B, K, 2)
@@ -606,7 +745,7 @@ def test_decode_keypoint_un_pnp_one_pass_equals_the_two_calls(oracle, synth, pkg
     for a, b in ((mask, mask2), (kpt, kpt2), (cov, cov2), (w, w2), (win, win2), (tnn, tn2)):
         assert torch.equal(a, b)
     want = oracle.ransac_voting_layer_v3(_np(mask_ref), _np(vertex), hn, 0.99, idxs=_np(idxs), singular=policy)
-    np.testing.assert_allclose(_np(kpt), want, rtol=0, atol=ATOL)
+    tol.assert_means_close(_np(kpt), want)
     _m, want_cov = oracle.estimate_voting_distribution_with_mean(_np(mask_ref), _np(vertex), want, hn_est, hn_est,
                                                                  idxs=_np(idxs_est))
     np.testing.assert_allclose(_np(cov), want_cov, rtol=1e-3, atol=1e-3)    # mean differs by <= 1e-4 px from the oracle's
@@ -753,7 +892,7 @@ def test_whole_call_can_be_captured_in_a_hip_graph(oracle, synth, pkg, gpu):
     np.testing.assert_array_equal(_np(out), _np(eager))
     np.testing.assert_array_equal(_np(win), _np(win_e))
     want = oracle.ransac_voting_layer_v3(_np(d["mask"]), _np(d["vertex"]), 512, 0.99, idxs=_np(idxs))
-    np.testing.assert_allclose(_np(out), want, rtol=0, atol=ATOL)
+    tol.assert_means_close(_np(out), want)
 
 
 def _soak_cases():
@@ -796,7 +935,7 @@ def test_randomized_soak_all_counts_bit_exact(oracle, synth, pkg, gpu, case):
     out, win, t2, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), hn, thresh, 5, 30000, idxs.to(gpu), None, 0,
                                              ext.SINGULAR_ZERO)
     want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, thresh, idxs=_np(idxs), singular="zero")
-    np.testing.assert_allclose(_np(out), want, rtol=1e-6, atol=ATOL)
+    tol.assert_means_close(_np(out), want)
 
 
 def test_foreground_sizes_around_tile_and_chunk_edges(oracle, pkg, gpu):
@@ -831,7 +970,7 @@ def test_foreground_sizes_around_tile_and_chunk_edges(oracle, pkg, gpu):
         np.testing.assert_array_equal(_np(counts[bi]), det[bi]["counts"].T, err_msg="tn = %d" % sizes[bi])
     out, win, _t, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), hn, 0.99, 5, 30000, idxs.to(gpu), None, 0, ext.SINGULAR_ZERO)
     want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, 0.99, idxs=_np(idxs), singular="zero")
-    np.testing.assert_allclose(_np(out), want, rtol=1e-6, atol=ATOL)
+    tol.assert_means_close(_np(out), want)
 
 
 def test_batches_beyond_1024_images_are_split_by_the_python_layer(oracle, pkg, gpu):
@@ -853,7 +992,7 @@ def test_batches_beyond_1024_images_are_split_by_the_python_layer(oracle, pkg, g
     for bi in (0, 5, 1023, 1024, 1029):                                   # both sides of the chunk boundary
         want = oracle.ransac_voting_layer_v3(_np(mask[bi:bi + 1]), _np(vertex[bi:bi + 1]), hn, 0.9, idxs=_np(idxs[bi:bi + 1]),
                                              singular="zero")
-        np.testing.assert_allclose(_np(out[bi:bi + 1]), want, rtol=1e-5, atol=ATOL)
+        tol.assert_means_close(_np(out[bi:bi + 1]), want)
     mean, cov = estimate_voting_distribution_with_mean(mask.to(gpu), vertex.to(gpu), out, 32, 32, inlier_thresh=0.9,
                                                        idxs=idxs.to(gpu))
     assert cov.shape == (B, K, 2, 2) and bool(torch.isfinite(cov).all())
@@ -927,7 +1066,7 @@ def test_float_masks_and_strided_slices(oracle, synth, pkg, gpu):
     fm = mask.float()
     fm[0, 0, 0] = 0.7
     got = ransac_voting_layer_v3(fm.to(gpu), vertex.to(gpu), 64, inlier_thresh=0.99, idxs=idxs.to(gpu))
-    np.testing.assert_allclose(_np(got), want, rtol=0, atol=ATOL)
+    tol.assert_means_close(_np(got), want)
     # (b) every second row/column of a 2x larger int32 mask, vertex as a slice of a padded tensor
     big_m = torch.zeros(2, 2 * H, 2 * W, dtype=torch.int32, device=gpu)
     big_m[:, ::2, ::2] = mask.to(gpu).int()
@@ -937,7 +1076,7 @@ def test_float_masks_and_strided_slices(oracle, synth, pkg, gpu):
     vview = big_v[:, 1:H + 1, 2:W + 2, 1:K + 1]
     assert not mview.is_contiguous() and not vview.is_contiguous()
     got = ransac_voting_layer_v3(mview, vview, 64, inlier_thresh=0.99, idxs=idxs.to(gpu))
-    np.testing.assert_allclose(_np(got), want, rtol=0, atol=ATOL)
+    tol.assert_means_close(_np(got), want)
     # (c) estimate with a float mask: only entries == 1.0 are foreground
     fm2 = mask.float() * 1.0
     fm2[1][fm2[1] != 0] = 1.5
@@ -945,4 +1084,4 @@ def test_float_masks_and_strided_slices(oracle, synth, pkg, gpu):
     ii = synth.make_idxs([tn[0], 0], 128, K, seed=72)
     _m, wantc = oracle.estimate_voting_distribution_with_mean(_np(fm2), _np(vertex), _np(mean), 64, 128, idxs=_np(ii))
     _m2, cov = estimate_voting_distribution_with_mean(fm2.to(gpu), vertex.to(gpu), mean.to(gpu), 64, 128, idxs=ii.to(gpu))
-    np.testing.assert_allclose(_np(cov), wantc, rtol=1e-4, atol=ATOL)
+    tol.assert_cov_close(_np(cov), wantc)

@@ -1,0 +1,73 @@
+"""The ONE numerical tolerance of this repository (BASELINE.json: "within 1e-4 float tolerance"), and how it is applied.
+
+  keypoint means      |got - want| <= 1e-4 px + 2e-6 |want|
+  covariances         |got - want| <= 1e-4    + 2e-6 |want|      (against the oracle)
+                                     1e-4    + 5e-6 |want|      (against the reference's own float32 glue, see below)
+  everything integer  bit-exact (inlier counts, winner indices, tn, inlier bytes) -- and the float32 kernel outputs
+                      (hypotheses) too.
+
+Product vs ORACLE is asserted with exactly that rule (both accumulate the normal equations in binary64; the actual
+difference is ~1e-6).  Product / oracle vs the REFERENCE'S GLUE (tests/golden, produced by the reference's own
+ransac_voting_gpu.py) needs one more term: the reference accumulates ATA / ATb in binary32 (torch.matmul, sums of terms
+up to 1e7), and its own result deviates from the EXACT least-squares solution of the same inlier set by more than 1e-4
+on one fixture (v3_subsample: 1.8e-4 px on a coordinate of 4.4 px).  ``exact_v3`` computes that exact solution in
+rational arithmetic; the golden comparisons assert
+
+    |ours - golden| <= 1e-4 + 2e-6 |golden| + |golden - exact|            (elementwise)
+
+i.e. we are within the contract tolerance of the exact answer, and the remainder is the reference's own rounding, measured.
+tests/test_oracle.py::test_fp64_refit_is_the_one_closer_to_the_exact_solution pins the claim."""
+from fractions import Fraction
+
+import numpy as np
+
+MEAN_ATOL, MEAN_RTOL = 1e-4, 2e-6
+COV_ATOL, COV_RTOL = 1e-4, 2e-6
+COV_RTOL_VS_REFERENCE_F32 = 5e-6
+
+
+def assert_means_close(got, want, extra=None, what="keypoint means"):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    bound = MEAN_ATOL + MEAN_RTOL * np.abs(want) + (0 if extra is None else np.asarray(extra, np.float64))
+    bad = np.abs(got - want) > bound
+    assert not bad.any(), "%s: %d elements off by up to %.3g (bound %.3g there)" % (
+        what, int(bad.sum()), float(np.abs(got - want)[bad].max()), float(np.broadcast_to(bound, got.shape)[bad].min()))
+
+
+def assert_cov_close(got, want, rtol=COV_RTOL, what="covariances"):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    bad = np.abs(got - want) > COV_ATOL + rtol * np.abs(want)
+    assert not bad.any(), "%s: %d elements off by up to %.3g" % (what, int(bad.sum()), float(np.abs(got - want)[bad].max()))
+
+
+def exact_v3(oracle, mask, vertex, hn, thresh, idxs, selection=None, max_num=30000, min_num=5, singular="reference"):
+    """ransac_voting_layer_v3 with the refit (P:176-196) solved EXACTLY: the inlier set of every winner comes from the
+    oracle's bit-exact kernels, the normal equations and their 2x2 solution are rational arithmetic on the binary32
+    inputs, rounded to binary64 once at the end.  -> [B,K,2] float64."""
+    mask, vertex = np.asarray(mask), np.asarray(vertex, np.float32)
+    b, h, w, vn, _ = vertex.shape
+    out = np.zeros((b, vn, 2), np.float64)
+    for bi in range(b):
+        fg, coords, direct = oracle.compact_v3(mask[bi], vertex[bi], max_num, None if selection is None else selection[bi])
+        if fg < min_num:
+            continue
+        r = oracle.v3_image(direct, coords, idxs[bi], thresh)
+        tn = direct.shape[0]
+        inl = oracle.voting_for_hypothesis(direct, coords, r["win_pts"][None], np.zeros((1, vn, tn), np.uint8), thresh)[0]
+        sol, atb, sing = [], [], []
+        for vi in range(vn):
+            xx = xy = yy = bx = by = Fraction(0)
+            for ti in np.nonzero(inl[vi])[0]:
+                nx, ny = Fraction(float(direct[ti, vi, 1])), -Fraction(float(direct[ti, vi, 0]))
+                bb = nx * Fraction(float(coords[ti, 0])) + ny * Fraction(float(coords[ti, 1]))
+                xx += nx * nx; xy += nx * ny; yy += ny * ny
+                bx += nx * bb; by += ny * bb
+            det = xx * yy - xy * xy
+            atb.append((float(bx), float(by)))
+            sing.append(det == 0)
+            sol.append((0.0, 0.0) if det == 0 else (float((yy * bx - xy * by) / det), float((xx * by - xy * bx) / det)))
+        if singular == "reference" and any(sing):
+            out[bi] = np.array(atb)
+        else:
+            out[bi] = np.array(sol)
+    return out
