@@ -2,6 +2,8 @@
 
   libpvnet_vote.so   HIP kernels + C ABI (include/pvnet_vote.h), hipcc, no torch
   ransac_voting.so   pybind11/torch shim over that C ABI, host compiler only
+  libpvnet_nn.so     ADD-S nearest-neighbour search (include/pvnet_nn.h)
+  libpvnet_pnp.so    batched uncertainty-PnP refinement (include/pvnet_pnp.h)
 
 Both land next to this file so they travel with the source tree (a JIT cache
 under ~/.cache would not).  hipcc cross-compiles for gfx950 without a GPU.
@@ -19,6 +21,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpvnet_vote.so")
 EXT = os.path.join(HERE, "ransac_voting.so")
 NNLIB = os.path.join(HERE, "libpvnet_nn.so")
+PNPLIB = os.path.join(HERE, "libpvnet_pnp.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 # -ffp-contract=off is part of the numerical contract (bit-exact inlier counts), not a tuning flag.
@@ -67,6 +70,19 @@ def build_nn(force=False, verbose=False):
     return NNLIB
 
 
+def build_pnp(force=False, verbose=False):
+    """libpvnet_pnp.so: the batched uncertainty-PnP refinement (include/pvnet_pnp.h), hipcc, no torch.  binary64
+    throughout and not part of the bit-exactness contract: default fp-contract."""
+    src = os.path.join(CSRC, "pvnet_pnp.hip")
+    hdr = os.path.join(INCLUDE, "pvnet_pnp.h")
+    if not force and _newer(PNPLIB, src, hdr):
+        return PNPLIB
+    hipcc = shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
+    _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",
+          "-I" + INCLUDE, "-o", PNPLIB, src], verbose)
+    return PNPLIB
+
+
 def build_ext(force=False, verbose=False):
     src = os.path.join(CSRC, "ransac_voting_ext.cpp")
     hdr = os.path.join(INCLUDE, "pvnet_vote.h")
@@ -91,7 +107,7 @@ def build_ext(force=False, verbose=False):
 
 
 def build_all(force=False, verbose=False):
-    return build_lib(force, verbose), build_ext(force, verbose), build_nn(force, verbose)
+    return build_lib(force, verbose), build_ext(force, verbose), build_nn(force, verbose), build_pnp(force, verbose)
 
 
 if __name__ == "__main__":

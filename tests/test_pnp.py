@@ -1,0 +1,204 @@
+"""Uncertainty-weighted PnP refinement (second half).
+
+CPU (not gpu): the numpy oracle against the REFERENCE'S OWN functor (oracle/_ref/libref_uncertainty_pnp.so = its
+uncertainty_pnp.cpp compiled where it lies; residuals and Jacobians through the reference's vendored Jets), its
+Levenberg-Marquardt twin against the shim Solve() driving the reference's C entry point, and both against an
+independent minimiser (scipy / MINPACK); the C-ABI library loads and exports what include/pvnet_pnp.h declares.
+GPU: the HIP kernel (batched device entry, the reference's host symbol, the drop-in numpy functions) against the oracle.
+Parity is defined on the MINIMUM (cost within 1e-9 relative, pose within 1e-6 of the independent minimiser); with the
+default (Ceres) stopping rule the kernel equals its numpy twin iterate for iterate.  Ceres' own iterate path is unpinned.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import pnp_oracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KMAT = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1.0]])      # LINEMOD camera
+
+
+def problem(seed, pn=9, noise=1.0, perturb=(0.08, 0.08, 0.08, 0.01, 0.01, 0.04)):
+    """A PVNet-like instance: pn object keypoints a few cm apart, ~0.8 m from the camera, noisy detections with
+    per-keypoint anisotropic weights, and a perturbed start."""
+    rng = np.random.RandomState(seed)
+    P = rng.uniform(-0.06, 0.06, (pn, 3))
+    rt = np.concatenate([rng.uniform(-1.5, 1.5, 3), rng.uniform(-0.1, 0.1, 2), rng.uniform(0.6, 1.1, 1)])
+    X = np.array([po.angle_axis_rotate_point(rt[:3], p) for p in P]) + rt[3:]
+    p2 = np.stack([KMAT[0, 0] * X[:, 0] / X[:, 2] + KMAT[0, 2], KMAT[1, 1] * X[:, 1] / X[:, 2] + KMAT[1, 2]], 1)
+    p2 = p2 + rng.randn(pn, 2) * noise
+    W = np.stack([rng.uniform(0.2, 2.0, pn), rng.uniform(-0.3, 0.3, pn), rng.uniform(0.2, 2.0, pn)], 1)
+    init = rt + rng.randn(6) * np.array(perturb)
+    return p2, P, W, rt, init
+
+
+need_ref = pytest.mark.skipif(po.ref() is None, reason="oracle/_ref/libref_uncertainty_pnp.so not built (needs /root/reference)")
+
+
+@need_ref
+@pytest.mark.parametrize("seed", range(6))
+def test_oracle_residuals_and_jacobian_equal_the_reference_functor(seed):
+    p2, P, W, rt, init = problem(seed)
+    for q in (init, rt, np.concatenate([[1e-9, -2e-9, 5e-10], rt[3:]]), np.concatenate([[0.0, 0.0, 0.0], rt[3:]])):
+        r, J = po.residuals(q, p2, P, W, KMAT, True)
+        rr, JJ, c = po.ref_eval(q, p2, P, W, KMAT)                     # uncertainty_pnp.cpp:19-38 through ceres/jet.h
+        np.testing.assert_allclose(r, rr, rtol=1e-12, atol=1e-11)
+        np.testing.assert_allclose(J, JJ, rtol=1e-11, atol=1e-9 * np.abs(JJ).max())
+        assert abs(po.cost(q, p2, P, W, KMAT) - c) <= 1e-12 * max(c, 1.0)
+
+
+@need_ref
+@pytest.mark.parametrize("seed", range(6))
+def test_lm_twin_equals_the_reference_entry_point_and_reaches_the_independent_minimum(seed):
+    p2, P, W, rt, init = problem(seed)
+    x1, i1 = po.solve_lm(init, p2, P, W, KMAT)
+    x2, i2 = po.ref_solve(init, p2, P, W, KMAT)                        # the reference's uncertainty_pnp(): its functor, shim LM
+    assert i1["iterations"] == i2["iterations"] and i1["termination"] == i2["termination"]
+    np.testing.assert_allclose(x1, x2, rtol=0, atol=1e-12)
+    x3, i3 = po.solve_scipy(init, p2, P, W, KMAT)
+    # Ceres' default function tolerance (1e-6) stops a hair before the minimum: cost within 1e-9 of it
+    assert i1["final_cost"] <= i3["final_cost"] * (1 + 1e-9) + 1e-18 or abs(i1["final_cost"] - i3["final_cost"]) <= 1e-9 * i3["final_cost"]
+    assert np.abs(x1 - x3).max() < 1e-5
+    assert i1["final_cost"] < 0.2 * i1["initial_cost"]                 # and it did move
+
+
+def test_jacobian_matches_finite_differences():
+    p2, P, W, rt, init = problem(3)
+    r0, J = po.residuals(init, p2, P, W, KMAT, True)
+    for j in range(6):
+        h = 1e-6
+        e = np.zeros(6)
+        e[j] = h
+        fd = (po.residuals(init + e, p2, P, W, KMAT) - po.residuals(init - e, p2, P, W, KMAT)) / (2 * h)
+        np.testing.assert_allclose(J[:, :, j], fd, rtol=1e-6, atol=1e-5)
+
+
+def test_cabi_library_loads_and_exports_the_declared_symbols():
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pvnet_pnp.h")).read(), flags=re.S)
+    names = set(re.findall(r"\b([a-z_0-9]+)\s*\(", txt)) - {"defined"}
+    assert names == {"uncertainty_pnp", "pvp_uncertainty_pnp_batched"}
+    L = ctypes.CDLL(os.path.join(ROOT, "clean-pvnet_amd", "libpvnet_pnp.so"))
+    for n in names:
+        assert hasattr(L, n)
+    # bad arguments are refused before any launch (no GPU needed)
+    L.pvp_uncertainty_pnp_batched.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int] * 5 + [ctypes.c_double, ctypes.c_void_p]
+    assert L.pvp_uncertainty_pnp_batched(None, None, None, None, None, None, None, 1, 9, 0, 0, 0, 0.0, None) == -1
+
+
+def test_drop_in_import_path(pkg):
+    import inspect
+    from lib.csrc.uncertainty_pnp.un_pnp_utils import uncertainty_pnp, uncertainty_pnp_v2       # evaluators/linemod/pvnet.py:130
+    assert list(inspect.signature(uncertainty_pnp).parameters) == ["points_2d", "weights_2d", "points_3d", "camera_matrix"]
+    assert list(inspect.signature(uncertainty_pnp_v2).parameters) == ["points_2d", "covars", "points_3d", "camera_matrix", "type"]
+
+
+def test_dlt_start_is_inside_the_basin(pkg):
+    from clean_pvnet_amd.un_pnp_utils import initial_pose_dlt, rodrigues, rotation_to_angle_axis
+    for seed in range(5):
+        p2, P, W, rt, _ = problem(seed, noise=0.5)
+        init = initial_pose_dlt(P, p2, KMAT)
+        assert np.abs(rodrigues(init[:3]) - rodrigues(rt[:3])).max() < 0.8 and np.abs(init[3:] - rt[3:]).max() < 0.3   # crude (near-affine geometry), but
+        x, info = po.solve_lm(init, p2, P, W, KMAT)                                         # ... the refinement gets home from it
+        xs, _ = po.solve_scipy(rt, p2, P, W, KMAT)
+        assert np.abs(rodrigues(x[:3]) - rodrigues(xs[:3])).max() < 1e-5 and np.abs(x[3:] - xs[3:]).max() < 1e-5
+        w = np.random.RandomState(seed).uniform(-2, 2, 3)
+        np.testing.assert_allclose(rotation_to_angle_axis(rodrigues(w)), w, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_gpu_batched_equals_the_lm_twin_and_reaches_the_minimum(pkg, gpu):
+    import torch
+    from clean_pvnet_amd.un_pnp_utils import uncertainty_pnp_batched
+    probs = [problem(s, pn=pn, noise=n) for s, pn, n in [(0, 9, 1.0), (1, 9, 0.2), (2, 9, 3.0), (3, 4, 0.5), (4, 17, 1.0),
+                                                         (5, 9, 0.0), (6, 70, 1.0)]]
+    for pn in sorted({p[1].shape[0] for p in probs}):
+        grp = [p for p in probs if p[1].shape[0] == pn]
+        p2 = torch.tensor(np.stack([g[0] for g in grp]), device=gpu)
+        P = torch.tensor(np.stack([g[1] for g in grp]), device=gpu)
+        W = torch.tensor(np.stack([g[2] for g in grp]), device=gpu)
+        init = torch.tensor(np.stack([g[4] for g in grp]), device=gpu)
+        rt, info = uncertainty_pnp_batched(p2, W, P, torch.tensor(KMAT, device=gpu), init, return_info=True)
+        rt_min = uncertainty_pnp_batched(p2, W, P, torch.tensor(KMAT, device=gpu), init, max_iterations=200, function_tolerance=1e-15)
+        rt, info, rt_min = rt.cpu().numpy(), info.cpu().numpy(), rt_min.cpu().numpy()
+        for i, g in enumerate(grp):
+            x, inf = po.solve_lm(g[4], g[0], g[1], g[2], KMAT)            # same schedule: iterate for iterate
+            assert int(info[i, 2]) == inf["iterations"] and int(info[i, 3]) == inf["termination"]
+            np.testing.assert_allclose(rt[i], x, rtol=0, atol=1e-9)
+            np.testing.assert_allclose(info[i, :2], [inf["initial_cost"], inf["final_cost"]], rtol=1e-9, atol=1e-15)
+            xs, infs = po.solve_scipy(g[4], g[0], g[1], g[2], KMAT)       # the independent minimiser
+            c_min = po.cost(rt_min[i], g[0], g[1], g[2], KMAT)
+            assert abs(c_min - infs["final_cost"]) <= 1e-9 * max(infs["final_cost"], 1e-12) + 1e-18
+            np.testing.assert_allclose(rt_min[i], xs, rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_reference_symbol_and_drop_in_functions(pkg, gpu):
+    from clean_pvnet_amd.un_pnp_utils import _lib, rodrigues, uncertainty_pnp, uncertainty_pnp_v2
+    p2, P, W, rt, init = problem(11, noise=1.0)
+    out = np.zeros(6)
+    a = [np.ascontiguousarray(v, np.float64) for v in (p2, P, W, KMAT, init)]
+    _lib.uncertainty_pnp(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, a[4].ctypes.data,
+                         out.ctypes.data, 9)                                # the reference's C symbol, host pointers
+    x, _ = po.solve_lm(init, p2, P, W, KMAT)
+    np.testing.assert_allclose(out, x, rtol=0, atol=1e-9)
+    if po.ref() is not None:
+        xr, _ = po.ref_solve(init, p2, P, W, KMAT)                          # the reference's own entry point (shim LM)
+        np.testing.assert_allclose(out, xr, rtol=0, atol=1e-9)
+    Rt = uncertainty_pnp(p2.astype(np.float32), W.astype(np.float32), P.astype(np.float32), KMAT.astype(np.float32))
+    assert Rt.shape == (3, 4)
+    xs, _ = po.solve_scipy(rt, p2.astype(np.float32).astype(np.float64), P.astype(np.float32).astype(np.float64),
+                           W.astype(np.float32).astype(np.float64), KMAT.astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(Rt[:, :3], rodrigues(xs[:3]), atol=1e-5)
+    np.testing.assert_allclose(Rt[:, 3], xs[3:], atol=1e-5)
+    cov = np.stack([np.array([[2.0, 0.3], [0.3, 1.0]]) * s for s in np.linspace(0.5, 3, 9)])
+    cov[4] = 0                                                               # a keypoint without weight (cov[0,0] < 1e-5)
+    Rt2 = uncertainty_pnp_v2(p2, cov, P, KMAT)
+    w = np.array([0.0 if c[0, 0] < 1e-5 else 1 / np.linalg.eigvalsh(c).max() for c in cov])
+    xs2, _ = po.solve_scipy(rt, p2, P, np.stack([w, 0 * w, w], 1), KMAT)
+    np.testing.assert_allclose(Rt2[:, 3], xs2[3:], atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_pose_from_voted_keypoints_end_to_end(synth, pkg, gpu):
+    """decode_keypoint(un_pnp=True, weights=True) -> uncertainty_pnp_batched, everything on the device: the keypoints
+    the voting recovers, weighted by inv(sqrtm(cov)), give back the pose the field was rendered from."""
+    import torch
+    from clean_pvnet_amd.decode import decode_keypoint
+    from clean_pvnet_amd.un_pnp_utils import uncertainty_pnp_batched
+    B, H, W, K = 4, 240, 320, 9
+    rng = np.random.RandomState(5)
+    P = rng.uniform(-0.05, 0.05, (K, 3))
+    Kc = np.array([[300.0, 0, 160.0], [0, 300.0, 120.0], [0, 0, 1.0]])
+    rts = np.stack([np.concatenate([rng.uniform(-1, 1, 3), rng.uniform(-0.03, 0.03, 2), rng.uniform(0.5, 0.7, 1)]) for _ in range(B)])
+    kpts = []
+    for rt in rts:
+        X = np.array([po.angle_axis_rotate_point(rt[:3], p) for p in P]) + rt[3:]
+        kpts.append(np.stack([Kc[0, 0] * X[:, 0] / X[:, 2] + Kc[0, 2], Kc[1, 1] * X[:, 1] / X[:, 2] + Kc[1, 2]], 1))
+    kpts = torch.tensor(np.stack(kpts), dtype=torch.float32)
+    ys = torch.arange(H, dtype=torch.float32).view(H, 1)
+    xs = torch.arange(W, dtype=torch.float32).view(1, W)
+    x = torch.zeros(B, 2 + 2 * K, H, W)
+    for b in range(B):
+        c = kpts[b].mean(0)
+        m = ((xs - c[0]) ** 2 + (ys - c[1]) ** 2) <= 30.0 ** 2
+        x[b, 0] = 1.0
+        x[b, 1] = torch.where(m, torch.tensor(4.0), torch.tensor(-4.0))
+        g = torch.Generator().manual_seed(b)
+        for k in range(K):
+            dx, dy = kpts[b, k, 0] - xs, kpts[b, k, 1] - ys
+            n = torch.sqrt(dx * dx + dy * dy).clamp(min=1e-3)
+            x[b, 2 + 2 * k] = dx / n + 0.03 * torch.randn(H, W, generator=g)
+            x[b, 3 + 2 * k] = dy / n + 0.03 * torch.randn(H, W, generator=g)
+    x = x.to(gpu)
+    o = decode_keypoint({"seg": x[:, :2], "vertex": x[:, 2:]}, un_pnp=True, weights=True, seed=3)
+    assert float((o["kpt_2d"].cpu() - kpts).abs().max()) < 2.0
+    init = torch.tensor(rts + rng.randn(B, 6) * [0.05, 0.05, 0.05, 0.005, 0.005, 0.02], device=gpu)
+    rt = uncertainty_pnp_batched(o["kpt_2d"], o["var_weights"], torch.tensor(P, device=gpu), torch.tensor(Kc, device=gpu), init)
+    rt = rt.cpu().numpy()
+    for b in range(B):
+        R_err = np.abs(po.rodrigues(rt[b, :3]) - po.rodrigues(rts[b, :3])).max()
+        assert R_err < 0.05 and np.abs(rt[b, 3:] - rts[b, 3:]).max() < 0.03, (b, R_err, rt[b], rts[b])
