@@ -1,0 +1,14 @@
+#!/bin/bash
+# One gpurun call that produces everything tools/refresh_profiles.py copies into profiles/ for a round:
+#   gpurun --timeout 1500 -- 'bash tools/evidence.sh r2f'     then     python tools/refresh_profiles.py gpurun_out/prof_r2f gpurun_out/r2f r02
+set -u
+TAG=${1:-ev}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+bash tools/profile_bench.sh $TAG > $OUT/profile.log 2>&1
+python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python bench.py --no-cpu-baseline --extras --steps 50 > $OUT/bench_extras.json 2> $OUT/bench_extras.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_torchrun1.json 2> $OUT/bench_torchrun1.err
+python tools/config_bench.py --out $OUT/configs.json > $OUT/configs.log 2>&1
+bash tools/trace_rows.sh $TAG cfg2_B1 cfg3_B8_shard_of_8gpu cfg3_B64 default_path_hn128_maxnum100_B64 default_path_hn128_maxnum100_B1 > $OUT/gaps.log 2>&1
+tail -3 $OUT/profile.log; tail -c 600 $OUT/bench_default.json; grep -c "" $OUT/configs.log

@@ -1,12 +1,13 @@
 #!/usr/bin/env python
-"""Copy the judged summaries of one gpurun profiling session into profiles/ (round tag r01):
-    python tools/refresh_profiles.py gpurun_out/prof_<tag> gpurun_out/<dir with bench_default.json, bench_extras.json>
+"""Copy the judged summaries of one gpurun profiling session into profiles/ (round tag: third argument, default r02):
+    python tools/refresh_profiles.py gpurun_out/prof_<tag> gpurun_out/<dir with bench_default.json, bench_extras.json, configs.json> [r02]
 The session is produced on the GPU box by tools/profile_bench.sh <tag> plus `python bench.py [--extras]`."""
 import csv, glob, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof, fin = sys.argv[1], sys.argv[2]
-tmp = os.path.join(ROOT, "profiles", "r01_summary.json")
+TAG = sys.argv[3] if len(sys.argv) > 3 else "r02"
+tmp = os.path.join(ROOT, "profiles", TAG + "_summary.json")
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_prof.py"), prof, "--json", tmp],
                       stdout=subprocess.DEVNULL)
 
@@ -17,7 +18,7 @@ def short(n):
 
 
 rows = list(csv.DictReader(open(glob.glob(os.path.join(prof, "trace", "*kernel_stats.csv"))[0])))
-with open(os.path.join(ROOT, "profiles", "r01_kernel_stats.csv"), "w") as o:
+with open(os.path.join(ROOT, "profiles", TAG + "_kernel_stats.csv"), "w") as o:
     w = csv.writer(o)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
     for r in rows:
@@ -31,11 +32,18 @@ fetch, write = p["FETCH_SIZE"]["main_mean"], p["WRITE_SIZE"]["main_mean"]
 old.update({"FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "hbm_bytes_per_launch": int((fetch + write) * 1024),
             "images_per_launch": 64,
             "source": "%s (tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, python "
-                      "bench.py --steps 20 --warmup 5 --no-cpu-baseline), final tree of round 1" % prof})
+                      "bench.py --steps 20 --warmup 5 --no-cpu-baseline), round tag %s" % (prof, TAG)})
 json.dump(old, open(pmc_path, "w"), indent=1)
-for a, b in (("bench_default", "r01_bench_default"), ("bench_extras", "r01_bench_extras")):
+for a, b in (("bench_default", TAG + "_bench_default"), ("bench_extras", TAG + "_bench_extras"),
+             ("bench_torchrun1", TAG + "_bench_torchrun_1rank")):
+    if not os.path.exists(os.path.join(fin, a + ".json")):
+        continue
     line = [l for l in open(os.path.join(fin, a + ".json")) if l.startswith("{")][-1]
     json.dump(json.loads(line), open(os.path.join(ROOT, "profiles", b + ".json"), "w"), indent=1)
+if os.path.exists(os.path.join(fin, "configs.json")):
+    json.dump(json.load(open(os.path.join(fin, "configs.json"))), open(os.path.join(ROOT, "profiles", TAG + "_configs.json"), "w"), indent=1)
+for extra in glob.glob(os.path.join(fin, "gaps_*.json")):
+    json.dump(json.load(open(extra)), open(os.path.join(ROOT, "profiles", TAG + "_" + os.path.basename(extra)), "w"), indent=1)
 k = summ["kernel_stats"]
 g = p["GRBM_GUI_ACTIVE"]["main_mean"] / 8
 print("k_count_bf16 avg_us %.2f  VALU insts %.3g  VALU busy %.3f  clock GHz %.2f" % (
