@@ -151,16 +151,27 @@ def test_reference_pin_is_built():
 
 
 def test_bench_line_contract_on_the_committed_evidence():
-    """The JSON line bench.py printed on the MI355X (profiles/r01_bench_default.json) carries every field of the driver's
-    contract, the BASELINE.json metric, and numbers that are consistent with each other."""
+    """The JSON line bench.py printed on the MI355X (profiles/r02_bench_default.json; r02_bench_torchrun_1rank.json is the
+    same command under torch.distributed.run with a one-rank RCCL group) carries every field of the driver's contract,
+    the BASELINE.json metric, and numbers that are consistent with each other."""
     import json
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_default.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")))
+    tr = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_torchrun_1rank.json")))
+    assert tr["extra"]["rccl_ranks"] == 1 and "all_gather_into_tensor" in tr["extra"]["exchange"] and tr["n_gpus"] == 1
+    assert abs(tr["ms_per_step"] - line["ms_per_step"]) / line["ms_per_step"] < 0.15        # the exchange is a few microseconds
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
     assert "workload" in line["config"] and "model" not in line["config"]
-    assert line["unit"] == "images/s" and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["unit"] == "images/s" and line["higher_is_better"] is True and line["scaling"] == "strong"
+    assert line["config"]["global_batch"] == 64 and line["config"]["batch_per_gpu"] * line["n_gpus"] == 64
+    s = line["step_ms"]
+    assert s["p10"] <= s["median"] <= s["p90"] and abs(s["median"] - line["ms_per_step"]) / line["ms_per_step"] < 0.1
+    assert line["extra"]["rotating_batches"] >= 3
+    v = line["roofline_valu"]
+    assert v["bound"] == "valu_issue" and 0 < v["frac"] < 1 and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-3
+    assert "static" in line["roofline"]["traffic_source"]
     assert line["metric"].split(" (")[0] in base["metric"] or "images/sec" in base["metric"]
     r = line["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):

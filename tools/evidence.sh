@@ -6,6 +6,11 @@ TAG=${1:-ev}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 bash tools/profile_bench.sh $TAG > $OUT/profile.log 2>&1
+# the raw rocprofv3 output is tens of MB (gpurun merges at most 64 MiB back): summarise here, keep the stats CSV only
+python tools/summarize_prof.py $PWD/gpurun_out/prof_$TAG --json $OUT/prof_summary.json > $OUT/prof_summary.txt 2>&1
+cp $(find $PWD/gpurun_out/prof_$TAG/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_raw.csv 2>/dev/null
+du -sh $PWD/gpurun_out/prof_$TAG >> $OUT/profile.log
+rm -rf $PWD/gpurun_out/prof_$TAG
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --no-cpu-baseline --extras --steps 50 > $OUT/bench_extras.json 2> $OUT/bench_extras.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_torchrun1.json 2> $OUT/bench_torchrun1.err

@@ -8,8 +8,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof, fin = sys.argv[1], sys.argv[2]
 TAG = sys.argv[3] if len(sys.argv) > 3 else "r02"
 tmp = os.path.join(ROOT, "profiles", TAG + "_summary.json")
-subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_prof.py"), prof, "--json", tmp],
-                      stdout=subprocess.DEVNULL)
+if os.path.isdir(os.path.join(prof, "trace")):
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_prof.py"), prof, "--json", tmp],
+                          stdout=subprocess.DEVNULL)
+    stats_csv = glob.glob(os.path.join(prof, "trace", "*kernel_stats.csv"))[0]
+else:      # tools/evidence.sh summarised on the GPU box (the raw output does not fit gpurun's 64 MiB merge limit)
+    json.dump(json.load(open(os.path.join(fin, "prof_summary.json"))), open(tmp, "w"), indent=1)
+    stats_csv = os.path.join(fin, "kernel_stats_raw.csv")
 
 
 def short(n):
@@ -17,7 +22,7 @@ def short(n):
     return m.group(1) if m else None
 
 
-rows = list(csv.DictReader(open(glob.glob(os.path.join(prof, "trace", "*kernel_stats.csv"))[0])))
+rows = list(csv.DictReader(open(stats_csv)))
 with open(os.path.join(ROOT, "profiles", TAG + "_kernel_stats.csv"), "w") as o:
     w = csv.writer(o)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
