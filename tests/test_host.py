@@ -177,7 +177,7 @@ def test_bench_line_contract_on_the_committed_evidence():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) < 1.0
+    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) < 2.0       # kernel_ms_avg is rounded to 4 digits
     assert r["traffic"] is None or 0 < r["traffic"] < r["algorithmic_bytes"]          # no wasted re-reads
     c = line["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
