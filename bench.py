@@ -58,6 +58,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64, help="GLOBAL batch (images over all GPUs)")
     ap.add_argument("--rotate", type=int, default=3, help="distinct device-resident batches the steps cycle over")
+    ap.add_argument("--prewarm-ms", type=float, default=60.0,
+                    help="untimed steps run for this long BEFORE the --warmup steps: after the (GPU-idle) data generation the "
+                         "chip needs ~60-100 steps (20-30 ms) to reach steady clocks -- tools/clock_ramp.py: 0.335 ms/step at "
+                         "step 8, 0.300 at step 30, 0.279 from step 60 on -- so a 25-step run would time the ramp, not the path")
     ap.add_argument("--config", default="cfg3", help="image shape / K / hn / foreground of this BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the weak-scaling and overlapped variants")
@@ -110,8 +114,25 @@ def main():
             return torch.zeros((0, K, 2), device=dev)
         return ransac_voting_layer_v3(d["mask"], d["vertex"], hn, inlier_thresh=thresh)
 
+    prewarm_done = [0]
+
     def run(step_fn, warmup, steps):
-        """W untimed + exactly K timed steps, barrier + synchronize on both sides, max over ranks; per-step HIP events."""
+        """(clock pre-warm, untimed) + W untimed + exactly K timed steps, barrier + synchronize on both sides, max over
+        ranks; per-step HIP events."""
+        if args.prewarm_ms > 0:
+            t_pre = time.perf_counter()
+            n_pre = 0
+            while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms or n_pre % 8:
+                step_fn(n_pre)                 # a multiple of 8 steps on every rank (collectives stay matched) ...
+                n_pre += 1
+                if n_pre % 8 == 0:
+                    torch.cuda.synchronize()   # ... and the clock is read with the queue drained
+                    if use_dist:               # same count everywhere: rank 0 decides
+                        flag = torch.tensor([1.0 if (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms else 0.0], device=dev)
+                        dist.broadcast(flag, 0)
+                        if flag.item() == 0.0:
+                            break
+            prewarm_done[0] = max(prewarm_done[0], n_pre)
         for i in range(warmup):
             step_fn(i)
         if use_dist:
@@ -236,6 +257,8 @@ def main():
         extra = {"tn_mean": round(float(tn_cpu.float().mean()), 1) if tn_cpu.numel() else 0.0,
                  "known_answer_max_err_px": round(err, 3),
                  "rotating_batches": len(batches), "bytes_per_batch_per_gpu": int(B * H * W * (8 + K * 8)),
+                 "prewarm": {"ms": args.prewarm_ms, "untimed_steps": prewarm_done[0],
+                             "why": "clock ramp after the GPU-idle data generation (tools/clock_ramp.py); the timed region is exactly --steps steps"},
                  "images_per_gpu": B, "rccl_ranks": rccl_ranks, "per_rank_count_kernel_ms": per_rank_kernel_ms,
                  "exchange": ("all_gather_into_tensor of [%d,%d,2] f32 inside every step" % (global_batch, K)) if use_dist else None}
         if weak:
