@@ -44,7 +44,9 @@ def samples(n, T, seed, spread):
 
 @pytest.mark.parametrize("T", [0.9, 0.99, 0.999])
 def test_packed_valu_band(T):
-    """k_count_fast: d = fl(h-c); nh, B binary64 quotients rounded once; a = fma(dx,nhx, dy*nhy); t = a - |b'|."""
+    """The sqrt/divide-free decision on f32 operands (round 1's k_count_fast, now the model of k_count_bf16's second level,
+    whose f32-computed unit normals get the wider beta2): d = fl(h-c); nh, B binary64 quotients rounded once;
+    a = fma(dx,nhx, dy*nhy); t = a - |b'|."""
     n = 2_000_000
     Td = np.float64(f32(T)); s2 = 1 - Td * Td; kappa = Td / np.sqrt(s2)
     beta = f32(1.25 * (3 * (1 + kappa) + 8 / s2) * U / Td)
