@@ -369,6 +369,38 @@ def extras_leg(extra, data, out, ext, synth, ransac_voting_layer_v3, estimate_vo
             fn()
         torch.cuda.synchronize()
         extra[name] = round(B * 20 / (time.perf_counter() - t3), 1)
+    # the whole post-network step of one frame with cfg.test.un_pnp (resnet18.py:65-72 + evaluators/linemod/pvnet.py:118-132):
+    # fused decode_keypoint (mask, keypoints, covariances, PnP weights) + the batched uncertainty-PnP refinement, B = 1 and B
+    from clean_pvnet_amd.un_pnp_utils import uncertainty_pnp_batched
+    import numpy as _np
+    rng0 = _np.random.RandomState(1)
+    kpt3d = torch.tensor(rng0.uniform(-0.06, 0.06, (K, 3)), device=dev)
+    Kcam = torch.tensor([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1.0]], device=dev, dtype=torch.float64)
+    for nb, tag in ((1, "B1"), (B, "B%d" % B)):
+        segb, verb = seg[:nb], ver[:nb]
+        init = torch.tensor(_np.tile(_np.array([0.1, -0.2, 0.3, 0.0, 0.0, 0.8]), (nb, 1)), device=dev)
+
+        def frame():
+            o = decode_keypoint({"seg": segb, "vertex": verb}, un_pnp=True, weights=True)
+            return uncertainty_pnp_batched(o["kpt_2d"], o["var_weights"], kpt3d, Kcam, init)
+        for _ in range(3):
+            frame()
+        torch.cuda.synchronize()
+        t7 = time.perf_counter()
+        nrep = 50 if nb == 1 else 10
+        for _ in range(nrep):
+            frame()
+        torch.cuda.synchronize()
+        extra["un_pnp_decode_plus_pnp_%s_ms_per_call" % tag] = round(1e3 * (time.perf_counter() - t7) / nrep, 4)
+        o = decode_keypoint({"seg": segb, "vertex": verb}, un_pnp=True, weights=True)
+        for _ in range(3):
+            uncertainty_pnp_batched(o["kpt_2d"], o["var_weights"], kpt3d, Kcam, init)
+        torch.cuda.synchronize()
+        t8 = time.perf_counter()
+        for _ in range(50):
+            uncertainty_pnp_batched(o["kpt_2d"], o["var_weights"], kpt3d, Kcam, init)
+        torch.cuda.synchronize()
+        extra["uncertainty_pnp_batched_%s_ms_per_call" % tag] = round(1e3 * (time.perf_counter() - t8) / 50, 4)
     # the ADD-S nearest-neighbour search at a LINEMOD-sized model (5841 points, both clouds)
     import numpy as np
     from clean_pvnet_amd.nn_utils import find_nearest_point_idx
