@@ -241,8 +241,13 @@ CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
 
 int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st)
 {
-    if (use_bf16_count(p)) return launch_count_bf16(p, L, ws, st);
-    return launch_count(planar_count_args(p, L, ws), st);
+    if (p->ev_count_begin && hipEventRecord((hipEvent_t)p->ev_count_begin, st) != hipSuccess)
+        return fail(PVV_E_ARG, "ev_count_begin is not a valid hipEvent_t");
+    const int e = use_bf16_count(p) ? launch_count_bf16(p, L, ws, st) : launch_count(planar_count_args(p, L, ws), st);
+    if (e) return e;
+    if (p->ev_count_end && hipEventRecord((hipEvent_t)p->ev_count_end, st) != hipSuccess)
+        return fail(PVV_E_ARG, "ev_count_end is not a valid hipEvent_t");
+    return PVV_OK;
 }
 
 template <int ES>

@@ -14,10 +14,12 @@
 // This file contains no device code; it is compiled by the host compiler only.
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
 #include <torch/extension.h>
 
 #include <optional>
 #include <tuple>
+#include <vector>
 
 #include "pvnet_vote.h"
 
@@ -372,6 +374,43 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> estimate_
     return {cov, hyp, counts, tn, weights};
 }
 
+// `reps` full ransac_voting_layer_v3 calls cycling over the given batches, each with a HIP event pair recorded around its
+// inlier-count launch (pvv_problem.ev_count_begin / ev_count_end) -> the kernel's duration inside the pipeline, ms per call.
+// One synchronisation at the end; a measurement aid (bench.py), not part of the voting path.
+std::vector<double> count_kernel_ms_in_pipeline(std::vector<at::Tensor> masks, std::vector<at::Tensor> vertices,
+                                                int64_t round_hyp_num, double inlier_thresh, int64_t min_num,
+                                                int64_t max_num, int64_t seed, int64_t reps)
+{
+    TORCH_CHECK(!masks.empty() && masks.size() == vertices.size(), "need as many masks as vertex fields");
+    const c10::DeviceGuard device_guard(vertices[0].device());
+    std::vector<hipEvent_t> ev(2 * (size_t)reps);
+    for (auto &e : ev) TORCH_CHECK(hipEventCreate(&e) == hipSuccess, "hipEventCreate failed");
+    std::vector<at::Tensor> keep;
+    for (int64_t r = 0; r < reps; ++r) {
+        const at::Tensor &mask = masks[r % masks.size()], &vertex = vertices[r % masks.size()];
+        pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, PVV_SINGULAR_REFERENCE,
+                                     seed + r);
+        p.ev_count_begin = (void *)ev[2 * r];
+        p.ev_count_end = (void *)ev[2 * r + 1];
+        at::Tensor ws = make_workspace(p, vertex);
+        auto out = at::empty({p.B, p.K, 2}, vertex.options());
+        ok(pvv_ransac_voting_v3(&p, mask.data_ptr(), vertex.data_ptr<float>(), nullptr, nullptr, ws.data_ptr(),
+                                (size_t)ws.numel(), out.data_ptr<float>(), nullptr, nullptr, cur_stream(vertex)),
+           "ransac_voting_v3");
+        keep.push_back(ws);
+        keep.push_back(out);
+    }
+    TORCH_CHECK(hipStreamSynchronize((hipStream_t)cur_stream(vertices[0])) == hipSuccess, "hipStreamSynchronize failed");
+    std::vector<double> ms((size_t)reps);
+    for (int64_t r = 0; r < reps; ++r) {
+        float t = 0.f;
+        TORCH_CHECK(hipEventElapsedTime(&t, ev[2 * r], ev[2 * r + 1]) == hipSuccess, "hipEventElapsedTime failed");
+        ms[(size_t)r] = t;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return ms;
+}
+
 // Re-run only the inlier-count kernel on the state a previous ransac_voting_v3 call left in `ws`
 // (bench.py brackets this with HIP events to get the dominant kernel's duration).
 void rerun_count_kernel(at::Tensor mask, at::Tensor vertex, int64_t hn, double inlier_thresh, int64_t min_num,
@@ -418,6 +457,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("hyp_total"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"), py::arg("idxs"),
           py::arg("selection"), py::arg("seed"), py::arg("want_hyp"), py::arg("first_image") = 0, py::arg("count_kernel") = 0);
     m.def("rerun_count_kernel", &rerun_count_kernel, "re-launch the inlier-count kernel (profiling aid)");
+    m.def("count_kernel_ms_in_pipeline", &count_kernel_ms_in_pipeline,
+          "duration of the inlier-count kernel inside full v3 calls, HIP events around its launch (profiling aid)",
+          py::arg("masks"), py::arg("vertices"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"),
+          py::arg("max_num"), py::arg("seed"), py::arg("reps"));
     m.attr("abi_version") = pvv_abi_version();
     m.attr("SINGULAR_REFERENCE") = (int)PVV_SINGULAR_REFERENCE;
     m.attr("SINGULAR_ZERO") = (int)PVV_SINGULAR_ZERO;

@@ -113,6 +113,10 @@ typedef struct pvv_problem {
                                 hypothesis' index pair resolved to, -1 where none (image skipped).  Lets a test
                                 replay the device RNG's draws through the oracle; for the fused un_pnp call hn is
                                 p->hn + hn_est */
+    void *ev_count_begin;    /* optional hipEvent_t pair (NULL = off), recorded on `stream` immediately before and   */
+    void *ev_count_end;      /* after the inlier-count launch of THIS call: the dominant kernel's duration as it runs
+                                inside the pipeline (bench.py's roofline figure; re-launching the kernel alone back to
+                                back heats the chip and reads ~10 % longer) */
 } pvv_problem;
 
 /* pvv_problem.count_kernel.  AUTO: the split-bf16 matrix-core prefilter with its guard band wherever it is valid

@@ -20,7 +20,7 @@ class Problem(ctypes.Structure):
                 ("singular_policy", c_i32), ("inlier_thresh", c_f32),
                 ("mask_stride", c_i64 * 3), ("vertex_stride", c_i64 * 5), ("seed", c_u64),
                 ("seg_classes", c_i32), ("first_image", c_i32), ("seg_stride", c_i64 * 4),
-                ("count_kernel", c_i32), ("reserved0", c_i32), ("d_draws_out", vp)]
+                ("count_kernel", c_i32), ("reserved0", c_i32), ("d_draws_out", vp), ("ev_count_begin", vp), ("ev_count_end", vp)]
 
 
 def declared_symbols():

@@ -9,6 +9,8 @@ bash tools/profile_bench.sh $TAG > $OUT/profile.log 2>&1
 # the raw rocprofv3 output is tens of MB (gpurun merges at most 64 MiB back): summarise here, keep the stats CSV only
 python tools/summarize_prof.py $PWD/gpurun_out/prof_$TAG --json $OUT/prof_summary.json > $OUT/prof_summary.txt 2>&1
 cp $(find $PWD/gpurun_out/prof_$TAG/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_raw.csv 2>/dev/null
+# the JSON line the PROFILED process itself printed: its HIP-event kernel time and rocprofv3's average are one process
+grep "^{" $PWD/gpurun_out/prof_$TAG/bench_trace.log | tail -1 > $OUT/bench_under_rocprof.json
 du -sh $PWD/gpurun_out/prof_$TAG >> $OUT/profile.log
 rm -rf $PWD/gpurun_out/prof_$TAG
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err

@@ -40,7 +40,7 @@ old.update({"FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "hbm_bytes_per_launc
                       "bench.py --steps 20 --warmup 5 --no-cpu-baseline), round tag %s" % (prof, TAG)})
 json.dump(old, open(pmc_path, "w"), indent=1)
 for a, b in (("bench_default", TAG + "_bench_default"), ("bench_extras", TAG + "_bench_extras"),
-             ("bench_torchrun1", TAG + "_bench_torchrun_1rank")):
+             ("bench_torchrun1", TAG + "_bench_torchrun_1rank"), ("bench_under_rocprof", TAG + "_bench_under_rocprof")):
     if not os.path.exists(os.path.join(fin, a + ".json")):
         continue
     line = [l for l in open(os.path.join(fin, a + ".json")) if l.startswith("{")][-1]
