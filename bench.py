@@ -195,21 +195,18 @@ def main():
                 "weak_scaling_ms_per_step": round(1e3 * w_el / n2, 4), "weak_batch_per_gpu": global_batch,
                 "strong_overlapped_exchange_images_per_s": round(global_batch * n2 / o_el, 1)}
 
-    # per-rank duration of the dominant kernel, HIP events on the launch stream: recorded around the inlier-count launch
-    # INSIDE full calls cycling over the rotating batches (pvv_problem.ev_count_begin/end) -- the kernel as it runs in the
-    # timed steps, and what rocprofv3 --kernel-trace averages for this command.  (Re-launching the kernel alone back to
-    # back, round 1's method, reads ~10 % longer on the same box: sustained matrix-core + VALU load lowers the clock;
-    # that figure is kept in `extra` for reference.)
-    k_ms, k_avg_ms, k_relaunch_ms, tn_cpu = [0.0], 0.0, 0.0, torch.zeros(0)
+    # per-rank duration of the dominant kernel, HIP events on the launch stream around groups of back-to-back re-launches
+    # of that kernel alone (pvv_rerun_count_kernel; the host's launch latency hides behind the previous launch, so the
+    # figure is the kernel's duration plus the ~1.5 us kernel boundary -- what rocprofv3 --kernel-trace reports for it).
+    # tools/count_kernel_timing.py shows this, a differential measurement (steps with one extra count launch), HIP events
+    # recorded around the launch inside full calls (pvv_problem.ev_count_begin/end) and rocprofv3's own timestamps of
+    # the in-pipeline launches agreeing within 2 % in one process; the events-inside-calls figure is reported in `extra`
+    # (it reads up to ~10 % long on some boxes and under the profiler: the event packets themselves).
+    k_ms, k_avg_ms, k_incall_ms, tn_cpu = [0.0], 0.0, 0.0, torch.zeros(0)
     if B > 0:
-        reps = 30
-        ext.count_kernel_ms_in_pipeline([d["mask"] for d in batches], [d["vertex"] for d in batches], hn, thresh, 5, 30000, 11, 6)
-        k_ms = sorted(ext.count_kernel_ms_in_pipeline([d["mask"] for d in batches], [d["vertex"] for d in batches], hn, thresh,
-                                                      5, 30000, 12, reps))
-        k_avg_ms = sum(k_ms) / len(k_ms)
         d0 = batches[0]
         _o, win, tn, ws = ext.ransac_voting_v3(d0["mask"], d0["vertex"], hn, thresh, 5, 30000, None, None, 1, ext.SINGULAR_REFERENCE)
-        groups, per_group = 3, 10
+        groups, per_group = 5, 10
         for _ in range(3):
             ext.rerun_count_kernel(d0["mask"], d0["vertex"], hn, thresh, 5, 30000, ws, False)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(groups)]
@@ -219,7 +216,10 @@ def main():
                 ext.rerun_count_kernel(d0["mask"], d0["vertex"], hn, thresh, 5, 30000, ws, False)
             b.record()
         torch.cuda.synchronize()
-        k_relaunch_ms = sum(a.elapsed_time(b) / per_group for a, b in evs) / groups
+        k_ms = sorted(a.elapsed_time(b) / per_group for a, b in evs)
+        k_avg_ms = sum(k_ms) / len(k_ms)
+        ic = ext.count_kernel_ms_in_pipeline([d["mask"] for d in batches], [d["vertex"] for d in batches], hn, thresh, 5, 30000, 12, 24)
+        k_incall_ms = sum(ic[6:]) / len(ic[6:])
         tn_cpu = torch.cat([ext.ransac_voting_v3(d["mask"], d["vertex"], hn, thresh, 5, 30000, None, None, 1,
                                                  ext.SINGULAR_REFERENCE)[2].cpu() for d in batches]).view(len(batches), -1)
         tn_cpu = tn_cpu.float().mean(0)                               # foreground pixels per image slot, mean over the batches
@@ -248,8 +248,8 @@ def main():
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": "k_count_bf16", "kernel_ms_avg": round(k_avg_ms, 4),
-                    "kernel_ms_median": round(k_ms[len(k_ms) // 2], 4), "kernel_ms_p10_p90": [round(pct(k_ms, 0.1), 4), round(pct(k_ms, 0.9), 4)],
-                    "kernel_ms_how": "HIP events recorded around the kernel's launch inside %d full calls over the rotating batches" % len(k_ms),
+                    "kernel_ms_median": round(k_ms[len(k_ms) // 2], 4),
+                    "kernel_ms_how": "HIP events on the launch stream around %d groups of 10 back-to-back re-launches of the kernel alone" % len(k_ms),
                     "algorithmic_bytes": alg_bytes,
                     "evaluations": evals, "gevals_per_s": round(evals / (k_avg_ms * 1e-3) / 1e9, 1) if k_avg_ms else 0.0,
                     "note": "contract figure (SURVEY 8d dense-field bytes / kernel time); the kernel reads the compacted "
@@ -269,7 +269,7 @@ def main():
                  "prewarm": {"ms": args.prewarm_ms, "untimed_steps": prewarm_done[0],
                              "why": "clock ramp after the GPU-idle data generation (tools/clock_ramp.py); the timed region is exactly --steps steps"},
                  "images_per_gpu": B, "rccl_ranks": rccl_ranks, "per_rank_count_kernel_ms": per_rank_kernel_ms,
-                 "count_kernel_ms_relaunched_alone": round(k_relaunch_ms, 4),
+                 "count_kernel_ms_events_inside_calls": round(k_incall_ms, 4),
                  "exchange": ("all_gather_into_tensor of [%d,%d,2] f32 inside every step" % (global_batch, K)) if use_dist else None}
         if weak:
             extra.update(weak)

@@ -115,8 +115,8 @@ typedef struct pvv_problem {
                                 p->hn + hn_est */
     void *ev_count_begin;    /* optional hipEvent_t pair (NULL = off), recorded on `stream` immediately before and   */
     void *ev_count_end;      /* after the inlier-count launch of THIS call: the dominant kernel's duration as it runs
-                                inside the pipeline (bench.py's roofline figure; re-launching the kernel alone back to
-                                back heats the chip and reads ~10 % longer) */
+                                inside the pipeline (a measurement aid: tools/count_kernel_timing.py compares it with
+                                re-launches of the kernel alone, a differential measurement and rocprofv3) */
 } pvv_problem;
 
 /* pvv_problem.count_kernel.  AUTO: the split-bf16 matrix-core prefilter with its guard band wherever it is valid
