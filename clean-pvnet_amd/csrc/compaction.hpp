@@ -263,9 +263,17 @@ struct HypArgs {
     int *counts;             // [B,K,hn]
     int32_t *draws_out;      // [B,K,hn,2] or null: the pixel (y*W+x) each index pair resolved to (tests)
     int blocks;              // hypothesis blocks per image
+    int *surv;               // [B, kSurvCap] scratch: the survivors of a heavily subsampled image (see k_compact_hyp)
 };
 
 constexpr int kHypRejectTries = 1 << 12;
+// Fused subsampling with a SMALL survival probability (e.g. a 0/255 byte mask: foreground_num sums the byte values,
+// P:126, so 6144 pixels of 255 are subsampled to ~117): rejection sampling would need ~1/prob tries per index, so below
+// kSurvMinProb every hypothesis block lists the image's survivors (few by construction: < total/64 <= 5120 for the
+// <= 160-tile images that fuse) in row-major order and draws from that list -- exactly randint(0, tn) over the subsampled
+// list.  Every hypothesis block of the image writes the SAME list to the image's scratch row and reads back what it wrote.
+constexpr float kSurvMinProb = 1.f / 64.f;
+constexpr int kSurvCap = 8192;
 
 // Row t of the image's (not yet written) compacted list -> pixel: search the inclusive tile prefix, then one read of
 // the tile's list.
@@ -346,6 +354,31 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
         // compaction (the host never fuses when index pairs are injected: those address the subsampled order).
         const bool sub = a.fuse_sub && fg > (long long)a.max_num;
         const float prob = sub ? (float)a.max_num / (float)fg : 2.f;
+        int nsurv = -1;                                           // >= 0: survivors listed in h.surv[b]
+        if (sub && prob < kSurvMinProb) {
+            int *sv = h.surv + (size_t)b * kSurvCap;
+            nsurv = 0;
+            for (int i = 0; i < a.T; ++i) {                       // block-uniform walk over the tiles, 256 entries a round
+                const int ni = s_prefix[i] - (i ? s_prefix[i - 1] : 0);
+                for (int e0 = 0; e0 < ni; e0 += kBlock) {
+                    const int e = e0 + threadIdx.x;
+                    const bool keep = e < ni && img_draws[(size_t)i * kTile + e] < prob;
+                    const unsigned long long m = __ballot(keep);
+                    __syncthreads();
+                    if (lane == 0) red[wave] = __popcll(m);
+                    __syncthreads();
+                    int off = nsurv;
+                    for (int w2 = 0; w2 < wave; ++w2) off += red[w2];
+                    off += __popcll(m & ((1ull << lane) - 1ull));
+                    if (keep && off < kSurvCap) sv[off] = i * kTile + (int)img_lists[(size_t)i * kTile + e];
+                    nsurv += red[0] + red[1] + red[2] + red[3];
+                }
+            }
+            nsurv = nsurv < kSurvCap ? nsurv : kSurvCap;
+            __threadfence_block();
+            __syncthreads();
+            if (nsurv < tn) tn = nsurv;                           // what the compaction blocks will report (cap applies there)
+        }
 
         const int gid = j * kBlock + threadIdx.x;                 // hypothesis (vi, hi) of image b
         if (gid >= v.K * h.hn) return;
@@ -376,6 +409,10 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
             if (!sub) {
                 p0 = select_pixel(s_prefix, a.T, img_lists, (int)(rng_u32(a.seed, stream, img, c) % (uint32_t)tn));
                 p1 = select_pixel(s_prefix, a.T, img_lists, (int)(rng_u32(a.seed, stream, img, c + 1u) % (uint32_t)tn));
+            } else if (nsurv >= 0) {
+                const int *sv = h.surv + (size_t)b * kSurvCap;
+                p0 = sv[rng_u32(a.seed, stream, img, c) % (uint32_t)tn];
+                p1 = sv[rng_u32(a.seed, stream, img, c + 1u) % (uint32_t)tn];
             } else {
                 p0 = p1 = -1;
                 for (int tr = 0; tr < kHypRejectTries && (p0 < 0 || p1 < 0); ++tr) {

@@ -71,7 +71,7 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
     int T;
-    size_t tiles, tile_list, tile_draw, tn, coords, dirs, hyps, counts, sums, total;
+    size_t tiles, tile_list, tile_draw, tn, surv, coords, dirs, hyps, counts, sums, total;
 };
 
 Layout make_layout(const pvv_problem *p)
@@ -85,6 +85,7 @@ Layout make_layout(const pvv_problem *p)
     L.tile_list = take(sizeof(unsigned short) * (size_t)p->B * L.T * kTile);
     L.tile_draw = take(sizeof(float) * (size_t)p->B * L.T * kTile);
     L.tn = take(sizeof(int) * (size_t)p->B);
+    L.surv = take(sizeof(int) * (size_t)p->B * kSurvCap);
     L.coords = take(sizeof(float2) * (size_t)p->B * p->cap);
     L.dirs = take(sizeof(float2) * (size_t)p->B * p->K * p->cap);
     L.hyps = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
@@ -311,6 +312,7 @@ Front make_front(const pvv_problem *p, int mode, const void *d_mask, const float
     h.counts = (int *)(ws + L.counts);
     h.draws_out = p->d_draws_out;
     h.blocks = (int)(((long long)p->K * p->hn + kBlock - 1) / kBlock);
+    h.surv = (int *)(ws + L.surv);
     return f;
 }
 

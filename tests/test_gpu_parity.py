@@ -504,16 +504,20 @@ def test_decode_keypoint_beyond_1024_images_and_sharding_invariance(synth, pkg, 
         assert float((whole["kpt_2d"][:8].cpu() - d["kpt_2d"]).abs().max()) < 4.0
 
 
-@pytest.mark.parametrize("max_num", [30000, 5000, 2000])
-def test_device_rng_draws_replayed_through_the_oracle(oracle, synth, pkg, gpu, max_num):
+@pytest.mark.parametrize("max_num,byte_mask", [(30000, False), (5000, False), (2000, False), (30000, True)])
+def test_device_rng_draws_replayed_through_the_oracle(oracle, synth, pkg, gpu, max_num, byte_mask):
     """The hypothesis blocks of k_compact_hyp with the DEVICE RNG (no injected index pairs -- the path production
     runs): pvv_problem.d_draws_out reports the pixel every draw resolved to; mapping those pixels to rows of the
     oracle's compacted list and injecting them reproduces hypotheses, all counts and means exactly.  max_num = 5000
     subsamples inside k_compact_hyp (max_num >= 1/16 of the image: the index pairs then come from rejection sampling over
-    the survivors), max_num = 2000 through k_tile_subsample (the lists are rewritten first)."""
+    the survivors), max_num = 2000 through k_tile_subsample (the lists are rewritten first).  byte_mask: a 0/255 uint8
+    mask -- foreground_num sums the byte VALUES (P:126), so 9216 pixels are subsampled to ~118 with probability 0.013:
+    too small for rejection sampling, the hypothesis blocks list the survivors instead."""
     import ctypes
     c = {**synth.CONFIGS["cfg2"], "B": 2, "H": 240, "W": 320, "fg": 0.12}
     d = synth.make_batch(**c, seed=31)
+    if byte_mask:
+        d["mask"] = (d["mask"] * 255).to(torch.uint8)
     mask, vertex = d["mask"].to(gpu), d["vertex"].to(gpu)
     B, H, W, K, hn = 2, 240, 320, c["K"], 256
     sel = torch.rand(B, H, W, generator=torch.Generator().manual_seed(5))          # injected: the oracle needs the same draws
@@ -534,14 +538,15 @@ def test_device_rng_draws_replayed_through_the_oracle(oracle, synth, pkg, gpu, m
     idxs = np.zeros((B, hn, K, 2), np.int32)
     for bi in range(B):
         fg, coords, direct = oracle.compact_v3(_np(mask[bi]), _np(vertex[bi]), max_num, _np(sel[bi]))
-        assert coords.shape[0] == int(tn[bi]) and (fg > max_num) == (max_num < 30000)
+        assert coords.shape[0] == int(tn[bi]) and (fg > max_num) == (max_num < 30000 or byte_mask)
+        assert not byte_mask or 60 < coords.shape[0] < 200
         row = -np.ones(H * W, np.int64)
         row[(coords[:, 1] * W + coords[:, 0]).astype(np.int64)] = np.arange(coords.shape[0])
         r = row[dr[bi]]                                            # [K,hn,2]
         assert (r >= 0).all(), "a draw resolved to a pixel that did not survive the subsample"
         idxs[bi] = r.transpose(1, 0, 2)
         # the draws are spread over the whole list (uniform index pairs, not stuck on a tile)
-        assert len(np.unique(r)) > 0.5 * min(coords.shape[0], hn * K)
+        assert len(np.unique(r)) > 0.5 * min(coords.shape[0], hn * K) or byte_mask
     _check_v3(oracle, out, win, tn, mask, vertex, torch.from_numpy(idxs), hn, 0.99, selection=sel, max_num=max_num)
 
 
