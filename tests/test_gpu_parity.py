@@ -911,7 +911,16 @@ def _soak_cases():
                           thresh=float(rng.choice([0.6, 0.9, 0.99, 0.995, 0.999, 0.9999])),
                           fg=float(rng.choice([0.01, 0.05, 0.2, 0.6])), sigma=float(rng.choice([0.0, 0.02, 0.1, 0.5])),
                           B=int(rng.choice([1, 2, 3])), seed=1000 + i))
+    kinds = ["int64", "uint8", "uint8x2", "int32", "bool", "int16"]          # the mask types the scan is instantiated for
+    for i, c in enumerate(cases):
+        c["mask_kind"] = kinds[i % len(kinds)]
     return cases
+
+
+def _mask_as(mask, kind):
+    if kind == "uint8x2":
+        return (mask != 0).to(torch.uint8) * 255
+    return mask.to(getattr(torch, kind))
 
 
 @pytest.mark.parametrize("case", _soak_cases(), ids=lambda c: "H%dW%dK%dhn%dT%g" % (c["H"], c["W"], c["K"], c["hn"], c["thresh"]))
@@ -920,27 +929,59 @@ def test_randomized_soak_all_counts_bit_exact(oracle, synth, pkg, gpu, case):
     and the hypotheses themselves must equal the oracle's, and the v3 means must be within 1e-4."""
     from clean_pvnet_amd import ransac_voting as ext
     c = dict(case)
-    thresh, hn, seed = c.pop("thresh"), c.pop("hn"), c.pop("seed")
+    thresh, hn, seed, kind = c.pop("thresh"), c.pop("hn"), c.pop("seed"), c.pop("mask_kind")
     d = synth.make_batch(**c, seed=seed)
-    mask, vertex = d["mask"], d["vertex"]
-    tn = [int(x) for x in (mask != 0).sum((1, 2))]
-    if min(tn) < 5:
+    mask, vertex = _mask_as(d["mask"], kind), d["vertex"]
+    tn = [int(x) for x in (mask != 0).sum((1, 2))]                # v3's foreground: non-zero
+    tn1 = [int(x) for x in (mask == 1).sum((1, 2))]               # estimate's: == 1
+    if min(tn1) < 5:
         pytest.skip("degenerate synthetic mask")
-    if max(tn) > 30000:
+    if max(int(m.to(torch.uint8).long().sum()) for m in mask) > 30000:
         pytest.skip("subsampled case: covered by test_full_hd_frame_with_subsampling (needs injected selection draws)")
-    idxs = synth.make_idxs(tn, hn, c["K"], seed=seed)
+    idxs = synth.make_idxs(tn1, hn, c["K"], seed=seed)
     mean = torch.zeros(c["B"], c["K"], 2)
     det = []
     oracle.estimate_voting_distribution_with_mean(_np(mask), _np(vertex), _np(mean), hn, hn, inlier_thresh=thresh,
                                                   idxs=_np(idxs), details=det)
     cov, hyp, counts, tnn = capi.estimate(mask.to(gpu), vertex.to(gpu), mean.to(gpu), hn, thresh, idxs=idxs.to(gpu))
+    assert tnn.tolist() == tn1
     for bi in range(c["B"]):
         np.testing.assert_array_equal(_np(counts[bi]), det[bi]["counts"].T)
         np.testing.assert_array_equal(_np(hyp[bi]), det[bi]["hypo_pts"].transpose(1, 0, 2))
+    idxs = synth.make_idxs(tn, hn, c["K"], seed=seed + 1)
     out, win, t2, _ws = ext.ransac_voting_v3(mask.to(gpu), vertex.to(gpu), hn, thresh, 5, 30000, idxs.to(gpu), None, 0,
                                              ext.SINGULAR_ZERO)
+    assert t2.tolist() == tn
     want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, thresh, idxs=_np(idxs), singular="zero")
     tol.assert_means_close(_np(out), want)
+
+
+def test_calls_on_two_streams_are_independent(synth, pkg, gpu):
+    """The library launches on the caller's stream and owns no global state: calls enqueued on two streams at once (each
+    with its own workspace, as the shim allocates them) give the results of the same calls made one after the other."""
+    from clean_pvnet_amd.ransac_voting_gpu import estimate_voting_distribution_with_mean, ransac_voting_layer_v3
+    da = synth.make_batch(**{**synth.CONFIGS["cfg2"], "B": 3}, seed=5, device=gpu)
+    db = synth.make_batch(**{**synth.CONFIGS["cfg1"], "B": 7}, seed=6, device=gpu)
+    ref_a = ransac_voting_layer_v3(da["mask"], da["vertex"], 512, inlier_thresh=0.99, seed=1)
+    ref_b = ransac_voting_layer_v3(db["mask"], db["vertex"], 64, inlier_thresh=0.99, seed=2)
+    ref_c = estimate_voting_distribution_with_mean(db["mask"], db["vertex"], ref_b, seed=3)[1]
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs_a, outs_b, outs_c = [], [], []
+    for _ in range(6):
+        with torch.cuda.stream(sa):
+            outs_a.append(ransac_voting_layer_v3(da["mask"], da["vertex"], 512, inlier_thresh=0.99, seed=1))
+        with torch.cuda.stream(sb):
+            ob = ransac_voting_layer_v3(db["mask"], db["vertex"], 64, inlier_thresh=0.99, seed=2)
+            outs_b.append(ob)
+            outs_c.append(estimate_voting_distribution_with_mean(db["mask"], db["vertex"], ob, seed=3)[1])
+    torch.cuda.synchronize()
+    for o in outs_a:
+        assert torch.equal(o, ref_a)
+    for o in outs_b:
+        assert torch.equal(o, ref_b)
+    for o in outs_c:
+        assert torch.equal(o, ref_c)
 
 
 def test_foreground_sizes_around_tile_and_chunk_edges(oracle, pkg, gpu):
