@@ -169,6 +169,19 @@ def main():
     # known-answer sanity of what was timed: voting recovers the keypoints the field was built from
     err = float((out[lo:hi] - last["kpt_2d"]).abs().max()) if B > 0 else 0.0
 
+    # N = 1 extra (never `value`): the same steps alternating over two streams, as a caller that decodes a sequence of
+    # batches would issue them -- the scan / compaction of step i+1 run under the (VALU-bound) count kernel of step i.
+    # Splitting ONE call over streams loses instead (tools/two_stream.py), so the library does not do that by itself.
+    two_stream = None
+    if not use_dist and B > 0:
+        side = [torch.cuda.Stream(), torch.cuda.Stream()]
+        def alternating_step(i):
+            with torch.cuda.stream(side[i & 1]):
+                return vote(batches[i % len(batches)])
+        n2 = max(10, args.steps // 2)
+        ts_el, _per, _o = run(alternating_step, 6, n2)
+        two_stream = {"two_stream_images_per_s": round(global_batch * n2 / ts_el, 1), "two_stream_ms_per_step": round(1e3 * ts_el / n2, 4)}
+
     # N > 1 extras: weak scaling (global_batch images PER GPU) and the exchange overlapped with the next step's voting
     weak = None
     if use_dist and world > 1 and not args.no_weak:
@@ -278,6 +291,8 @@ def main():
                  "exchange": ("all_gather_into_tensor of [%d,%d,2] f32 inside every step" % (global_batch, K)) if use_dist else None}
         if weak:
             extra.update(weak)
+        if two_stream:
+            extra.update(two_stream)
         if world == 1 and args.extras:
             extras_leg(extra, batches[0], out, ext, synth, ransac_voting_layer_v3, estimate_voting_distribution_with_mean,
                        B, H, W, K, hn, thresh, dev)
