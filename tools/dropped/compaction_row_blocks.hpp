@@ -1,0 +1,564 @@
+// compaction.hpp -- stages 1 and 2: mask scan, subsample, ordered compaction, hypothesis generation.
+// Part of the single translation unit pvnet_vote.hip (included inside its anonymous namespace); see that file
+// for the numerical contract and the reference citations (K = ransac_voting_kernel.cu, P = ransac_voting_gpu.py).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// Stage 1: foreground compaction (replaces sum / nonzero / masked_select / uniform_ of
+// P:125-144 and P:207-229), order = row-major order of torch.nonzero.
+//
+// The image is cut into tiles of kTile = 2048 consecutive pixels.  k_tile_scan -- the ONLY pass over the mask --
+// leaves per tile (i) one packed word: foreground pixels | weight sum << 12 (foreground_num of P:126 sums byte
+// VALUES), (ii) the tile's foreground pixels as an ordered list of 16-bit offsets and -- when subsampling is possible
+// -- (iii) each listed pixel's U(0,1) draw of P:136 / P:220 (injected or from the counter RNG keyed by (image, pixel)),
+// so that no later stage evaluates the generator or touches the selection tensor again.  Everything downstream works from
+// those lists: the subsample (k_tile_subsample, or fused into k_compact_hyp) filters them, the compaction blocks of
+// k_compact_hyp gather the vertex field through them, and its hypothesis blocks pick the t-th foreground pixel of an
+// image by a search in the tile prefix + ONE list read -- so hypotheses need not wait for the compaction and the
+// separate hypothesis launch of round 1 is gone.
+// ---------------------------------------------------------------------------------------------
+struct MaskArgs {
+    const void *mask;
+    const float *selection;  // [B,H,W] injected U(0,1) or nullptr
+    int64_t sb, sh, sw;      // element strides
+    int es;                  // element size in bytes
+    int contig;              // sh == W && sw == 1
+    int mode;                // 0: v3 (low byte != 0, weight = low byte)  1: estimate (== 1)
+    int W, HW, T;
+    int min_num, max_num, cap;
+    uint64_t seed;
+    int b0;                  // first_image: RNG key offset of image 0
+    int *tn_user;            // the caller's tn[B] (or nullptr): written beside the workspace copy, no D2D copy later
+    int fuse_sub;            // 1: k_compact_hyp applies the subsampling itself (no k_tile_subsample launch), see there
+    int want_draws;          // 1: subsampling is possible at all (max_num below the largest foreground_num the mask can
+                             //    have): k_tile_scan stores every foreground pixel's U(0,1) draw beside its list entry
+    // fused argmax (decode_keypoint): when seg != nullptr the mask value is argmax_c seg[b,c,y,x]
+    const float *seg;
+    long long *mask_out;     // [B,H,W] int64 or nullptr
+    int64_t gb, gc, gh, gw;  // element strides of seg
+    int C;
+};
+
+constexpr uint32_t kTileNzMask = 0xfffu;   // tiles[] word: foreground pixels (0..2048) | weight sum (<= 2048*255) << 12
+
+template <int ES>
+__device__ __forceinline__ uint64_t load_elem(const void *base, int64_t off)
+{
+    if (ES == 1) return ((const uint8_t *)base)[off];
+    if (ES == 2) return ((const uint16_t *)base)[off];
+    if (ES == 4) return ((const uint32_t *)base)[off];
+    return ((const uint64_t *)base)[off];
+}
+
+// torch.argmax over the class axis: first maximal index, a NaN beats everything (and the first NaN wins)
+__device__ __forceinline__ int argmax_class(const MaskArgs &a, int b, int p)
+{
+    const int y = p / a.W;
+    const int x = p - y * a.W;
+    const float *q = a.seg + (int64_t)b * a.gb + (int64_t)y * a.gh + (int64_t)x * a.gw;
+    float best = q[0];
+    int idx = 0;
+    for (int c = 1; c < a.C; ++c) {
+        const float v = q[(int64_t)c * a.gc];
+        if (v > best || (v != v && best == best)) { best = v; idx = c; }
+    }
+    return idx;
+}
+
+// weight of pixel p of image b: 0 = background; v3: low byte (P:125-126 sums the bytes), estimate: 1 (P:207-208).
+template <int ES>
+__device__ __forceinline__ int mask_weight(const MaskArgs &a, int b, int p)
+{
+    if (a.seg) {
+        const int idx = argmax_class(a, b, p);
+        if (a.mask_out) a.mask_out[(int64_t)b * a.HW + p] = idx;
+        return a.mode == 0 ? (idx & 0xFF) : (idx == 1 ? 1 : 0);
+    }
+    int64_t off;
+    if (a.contig) {
+        off = (int64_t)b * a.sb + p;
+    } else {
+        int y = p / a.W;
+        int x = p - y * a.W;
+        off = (int64_t)b * a.sb + (int64_t)y * a.sh + (int64_t)x * a.sw;
+    }
+    uint64_t v = load_elem<ES>(a.mask, off);
+    if (a.mode == 0) return (int)(v & 0xFF);
+    return v == 1 ? 1 : 0;
+}
+
+// U(0,1) draw of P:136 / P:220 for pixel p of image b.
+__device__ __forceinline__ float selection_draw(const MaskArgs &a, int b, int p)
+{
+    if (a.selection) return a.selection[(int64_t)b * a.HW + p];
+    return (float)(rng_u32(a.seed, 0u, (uint32_t)(a.b0 + b), (uint32_t)p) >> 8) * 0x1p-24f;
+}
+
+// Exclusive scan of the 32 (step, wave) segment counts of a tile by wave 0; seg[32] = the tile's total.
+// Call with all threads; contains the barriers.
+__device__ __forceinline__ void scan_segments(int *seg)
+{
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int c = lane < kTileSteps * 4 ? seg[lane] : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int n = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += n;
+        }
+        if (lane < kTileSteps * 4) seg[lane] = inc - c;
+        if (lane == kTileSteps * 4 - 1) seg[kTileSteps * 4] = inc;
+    }
+    __syncthreads();
+}
+
+// Pass 1 -- the ONLY pass that reads the mask.
+template <int ES>
+__global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__restrict__ tiles,
+                                                      unsigned short *__restrict__ tile_list,
+                                                      float *__restrict__ tile_draw)
+{
+    __shared__ int seg[kTileSteps * 4 + 1];
+    __shared__ int red[4];
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    unsigned long long m[kTileSteps];
+    int sum = 0;
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s) {
+        const int p = t * kTile + s * kBlock + threadIdx.x;
+        int w = 0;
+        if (p < a.HW) w = mask_weight<ES>(a, b, p);
+        m[s] = __ballot(w != 0);
+        if (lane == 0) seg[s * 4 + wave] = __popcll(m[s]);
+        sum += w;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    scan_segments(seg);
+    if (threadIdx.x == 0)
+        tiles[b * a.T + t] = (uint32_t)seg[kTileSteps * 4] | ((uint32_t)(red[0] + red[1] + red[2] + red[3]) << 12);
+    unsigned short *list = tile_list + ((size_t)b * a.T + t) * kTile;
+    float *draw = tile_draw + ((size_t)b * a.T + t) * kTile;
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s)
+        if ((m[s] >> lane) & 1ull) {
+            const int r = seg[s * 4 + wave] + __popcll(m[s] & ((1ull << lane) - 1ull));
+            list[r] = (unsigned short)(s * kBlock + threadIdx.x);
+            if (a.want_draws) draw[r] = selection_draw(a, b, t * kTile + s * kBlock + threadIdx.x);
+        }
+}
+
+// foreground_num of P:126 / P:208 (sum of the weights) and the number of foreground pixels of image b.
+struct ImageTotals { long long fg; int total; int before; };
+
+// One pass over the image's tile table and ONE block reduction for all three sums: foreground_num, the rows of the
+// tiles before tile t, and the image's row count.  redl: 4 long long, red: 8 int.
+__device__ __forceinline__ ImageTotals image_totals(const uint32_t *__restrict__ tiles, int b, int T, int t,
+                                                    long long *redl, int *red)
+{
+    long long fgs = 0;
+    int before = 0, total = 0;
+    for (int i = threadIdx.x; i < T; i += kBlock) {
+        const uint32_t w = tiles[b * T + i];
+        fgs += w >> 12;
+        const int c = (int)(w & kTileNzMask);
+        total += c;
+        if (i < t) before += c;
+    }
+    fgs = wave_sum(fgs);
+    before = wave_sum(before);
+    total = wave_sum(total);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane_id() == 0) { redl[wave] = fgs; red[wave] = before; red[4 + wave] = total; }
+    __syncthreads();
+    ImageTotals r;
+    r.fg = redl[0] + redl[1] + redl[2] + redl[3];
+    r.before = red[0] + red[1] + red[2] + red[3];
+    r.total = red[4] + red[5] + red[6] + red[7];
+    return r;
+}
+
+// Filter one tile's list by the subsample draw (keep iff U < prob), order kept: survivors land in out[] (LDS or
+// global, may alias nothing), their number is returned to every thread.  seg: kTileSteps*4+1 ints of LDS.
+__device__ __forceinline__ int filter_tile_list(int nz, float prob, const unsigned short *__restrict__ list,
+                                                const float *__restrict__ draw, unsigned short *out, int *seg)
+{
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    unsigned long long m[kTileSteps];
+    unsigned short off[kTileSteps];
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s) {
+        const int e = s * kBlock + threadIdx.x;
+        bool f = false;
+        off[s] = 0;
+        if (e < nz) {
+            off[s] = list[e];
+            f = draw[e] < prob;
+        }
+        m[s] = __ballot(f);
+        if (lane == 0) seg[s * 4 + wave] = __popcll(m[s]);
+    }
+    scan_segments(seg);
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s)
+        if ((m[s] >> lane) & 1ull) out[seg[s * 4 + wave] + __popcll(m[s] & ((1ull << lane) - 1ull))] = off[s];
+    return seg[kTileSteps * 4];
+}
+
+// P:135-138 / P:219-223 as its own pass (large images, or max_num so small that nearly every image is subsampled):
+// when foreground_num > max_num every foreground pixel survives with probability max_num/foreground_num (binary32
+// quotient).  Rewrites the tile's list in place and its count; tiles without foreground and images that are not
+// subsampled exit at once.
+__global__ __launch_bounds__(kBlock) void k_tile_subsample(MaskArgs a, uint32_t *__restrict__ tiles,
+                                                           unsigned short *__restrict__ tile_list,
+                                                           const float *__restrict__ tile_draw)
+{
+    __shared__ long long redl[4];
+    __shared__ int red[8];
+    __shared__ int seg[kTileSteps * 4 + 1];
+    __shared__ unsigned short keep[kTile];
+    const int t = blockIdx.x, b = blockIdx.y;
+    const uint32_t w = tiles[b * a.T + t];
+    const int nz = (int)(w & kTileNzMask);
+    if (nz == 0) return;
+    const ImageTotals tot = image_totals(tiles, b, a.T, t, redl, red);
+    if (tot.fg <= (long long)a.max_num) return;
+    const float prob = (float)a.max_num / (float)tot.fg;
+    unsigned short *list = tile_list + ((size_t)b * a.T + t) * kTile;
+    const int n = filter_tile_list(nz, prob, list, tile_draw + ((size_t)b * a.T + t) * kTile, keep, seg);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kBlock) list[i] = keep[i];
+    // In place: the other blocks of the image may still be reading the table, but they only use the weight sums
+    // (foreground_num), which this update keeps; the pixel COUNT is read by later kernels only.
+    if (threadIdx.x == 0) tiles[b * a.T + t] = (uint32_t)n | (w & ~kTileNzMask);
+}
+
+struct VertexArgs {
+    const float *vertex;
+    int64_t sb, sh, sw, sk, sc;
+    int K;
+    int vec2;  // sc == 1 and every other stride even: (x,y) is one aligned 8-byte load
+};
+
+__device__ __forceinline__ float2 load_vertex(const VertexArgs &v, int b, int y, int x, int vi)
+{
+    const float *src = v.vertex + (int64_t)b * v.sb + (int64_t)y * v.sh + (int64_t)x * v.sw + (int64_t)vi * v.sk;
+    if (v.vec2) return *(const float2 *)src;
+    return make_float2(src[0], src[v.sc]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2: hypotheses (replaces random_ P:145/P:235 + generate_hypothesis K:11-86); zeroes the inlier counters.
+// ---------------------------------------------------------------------------------------------
+struct HypArgs {
+    const int32_t *idxs;     // [B,hn_first,K,2] or null
+    const int32_t *idxs2;    // [B,hn-hn_first,K,2] or null (the estimate's rounds of a fused un_pnp call)
+    int hn, hn_first;        // hypotheses [0,hn_first) draw from idxs / RNG stream `stream`, the rest from idxs2 / `stream2`
+    uint32_t stream, stream2;
+    float2 *hyps;            // [B,K,hn]
+    int *counts;             // [B,K,hn]
+    int32_t *draws_out;      // [B,K,hn,2] or null: the pixel (y*W+x) each index pair resolved to (tests)
+    int blocks;              // hypothesis blocks per image
+    int row_blocks, rows;    // compaction blocks per image and rows per thread: row_blocks * rows * 256 >= cap
+    int *surv;               // [B, kSurvCap] scratch: the survivors of a heavily subsampled image (see k_compact_hyp)
+};
+
+constexpr int kHypRejectTries = 1 << 12;
+// Fused subsampling with a SMALL survival probability (e.g. a 0/255 byte mask: foreground_num sums the byte values,
+// P:126, so 6144 pixels of 255 are subsampled to ~117): rejection sampling would need ~1/prob tries per index, so below
+// kSurvMinProb every hypothesis block lists the image's survivors (few by construction: < total/64 <= 5120 for the
+// <= 160-tile images that fuse) in row-major order and draws from that list -- exactly randint(0, tn) over the subsampled
+// list.  Every hypothesis block of the image writes the SAME list to the image's scratch row and reads back what it wrote.
+constexpr float kSurvMinProb = 1.f / 64.f;
+constexpr int kSurvCap = 8192;
+
+// Row t of the image's (not yet written) compacted list -> pixel: search the inclusive tile prefix, then one read of
+// the tile's list.
+__device__ __forceinline__ int select_pixel(const int *prefix, int T, const unsigned short *__restrict__ lists /*of image b*/, int t,
+                                            size_t *entry = nullptr /*index of the list entry within the image's lists*/)
+{
+    int lo = 0, hi = T - 1;               // smallest i with prefix[i] > t
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    const int r = t - (lo ? prefix[lo - 1] : 0);
+    const size_t e = (size_t)lo * kTile + r;
+    if (entry) *entry = e;
+    return lo * kTile + (int)lists[e];
+}
+
+// inclusive prefix of image b's tile counts -> prefix[0..T) (LDS), foreground_num (P:126 / P:208: the sum of the weights)
+// and the image's row count.  256 tiles per round; ends with a barrier (prefix[] is published).  redl: 4 long long, red: 4 int.
+struct ImagePrefix { long long fg; int total; };
+
+__device__ __forceinline__ ImagePrefix image_prefix(const uint32_t *__restrict__ tiles, int b, int T, int *prefix,
+                                                    long long *redl, int *red)
+{
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    long long fgs = 0;
+    int carry = 0;
+    for (int base = 0; base < T; base += kBlock) {
+        const int i = base + threadIdx.x;
+        const uint32_t w = i < T ? tiles[b * T + i] : 0u;
+        fgs += w >> 12;
+        int inc = (int)(w & kTileNzMask);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int n = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += n;
+        }
+        if (base) __syncthreads();                                // red[] of the previous round is consumed
+        if (lane == 63) red[wave] = inc;
+        __syncthreads();
+        int off = carry;
+        for (int w2 = 0; w2 < wave; ++w2) off += red[w2];
+        if (i < T) prefix[i] = inc + off;
+        carry += red[0] + red[1] + red[2] + red[3];
+    }
+    fgs = wave_sum(fgs);
+    if (lane == 0) redl[wave] = fgs;
+    __syncthreads();
+    ImagePrefix r;
+    r.fg = redl[0] + redl[1] + redl[2] + redl[3];
+    r.total = carry;
+    return r;
+}
+
+// Ordered scatter + hypotheses, one launch, grid (h.blocks + h.row_blocks, B).  EVERY block starts with the image's tile
+// prefix (one load per thread + one scan: the item table of both roles); then
+//  * blocks x < h.blocks (hypotheses): 256 hypotheses each, straight from the tile lists and the vertex field.  First in
+//    the grid: their dependency chain (table, prefix, search, list entry, two gathers) is the longer one, so they
+//    should not also be dispatched last (-0.7 us at B = 64, -1.2 us at B = 8);
+//  * the other h.row_blocks blocks (compaction) own ROWS of the image's compacted arrays, h.rows per thread: row r -> pixel
+//    by a search in the prefix + one list read (as the hypotheses do), then coords[b][r] = (x,y) (P:140-141) and
+//    dirs[b][vi][r] = vertex[b,y,x,vi,:] (P:142-143, planar per keypoint so that the count kernel's loads are
+//    unit-stride), the K gathers of a row all in flight.  Row-owning blocks are balanced (a tile holds 0..2048 pixels) and
+//    there are cap/256/rows of them per image instead of one per tile: at 480x640 30 instead of 150, of which 6 (instead
+//    of ~45) have work -- round 2 measured this kernel as a queue of short-lived blocks (block lifetimes / resident
+//    slots), not as traffic.  Blocks beyond the image's rows leave after the prefix.
+//  * an image that IS subsampled inside this launch (a.fuse_sub and foreground_num > max_num: rare by construction, see
+//    make_front) keeps the tile-wise form: its row blocks walk the tiles x, x + row_blocks, ... filter each list by the
+//    stored draws and scatter the survivors behind those of the tiles before.
+// Dynamic LDS: T ints (the tile prefix).
+__global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v, HypArgs h,
+                                                        const uint32_t *__restrict__ tiles,
+                                                        const unsigned short *__restrict__ tile_list,
+                                                        const float *__restrict__ tile_draw,
+                                                        int *__restrict__ tn_out, float2 *__restrict__ coords,
+                                                        float2 *__restrict__ dirs)
+{
+    extern __shared__ int s_prefix[];
+    __shared__ long long redl[4];
+    __shared__ int red[8];
+    __shared__ int seg[kTileSteps * 4 + 1];
+    __shared__ unsigned short list[kTile];
+    const int b = blockIdx.y;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const unsigned short *img_lists = tile_list + (size_t)b * a.T * kTile;
+    const float *img_draws = tile_draw + (size_t)b * a.T * kTile;
+
+    const ImagePrefix ip = image_prefix(tiles, b, a.T, s_prefix, redl, red);
+    const long long fg = ip.fg;
+    const int total = ip.total;                                   // rows before any truncation at cap
+    int tn = total < a.cap ? total : a.cap;
+    if (fg < (long long)a.min_num) tn = 0;                        // P:129-132 / P:211-216
+
+    if ((int)blockIdx.x < h.blocks) {
+        // ------------------------------------------------------------------ hypothesis block
+        const int j = blockIdx.x;
+        // subsampling fused into this launch (a.fuse_sub): the lists still hold EVERY foreground pixel; a pixel
+        // survives iff its draw < prob.  The index pairs then come from rejection sampling -- uniform over the
+        // survivors, which is what randint(0, tn) over the subsampled list is -- so nothing has to wait for the
+        // compaction (the host never fuses when index pairs are injected: those address the subsampled order).
+        const bool sub = a.fuse_sub && fg > (long long)a.max_num;
+        const float prob = sub ? (float)a.max_num / (float)fg : 2.f;
+        int nsurv = -1;                                           // >= 0: survivors listed in h.surv[b]
+        if (sub && prob < kSurvMinProb) {
+            int *sv = h.surv + (size_t)b * kSurvCap;
+            nsurv = 0;
+            for (int i = 0; i < a.T; ++i) {                       // block-uniform walk over the tiles, 256 entries a round
+                const int ni = s_prefix[i] - (i ? s_prefix[i - 1] : 0);
+                for (int e0 = 0; e0 < ni; e0 += kBlock) {
+                    const int e = e0 + threadIdx.x;
+                    const bool keep = e < ni && img_draws[(size_t)i * kTile + e] < prob;
+                    const unsigned long long m = __ballot(keep);
+                    __syncthreads();
+                    if (lane == 0) red[wave] = __popcll(m);
+                    __syncthreads();
+                    int off = nsurv;
+                    for (int w2 = 0; w2 < wave; ++w2) off += red[w2];
+                    off += __popcll(m & ((1ull << lane) - 1ull));
+                    if (keep && off < kSurvCap) sv[off] = i * kTile + (int)img_lists[(size_t)i * kTile + e];
+                    nsurv += red[0] + red[1] + red[2] + red[3];
+                }
+            }
+            nsurv = nsurv < kSurvCap ? nsurv : kSurvCap;
+            __threadfence_block();
+            __syncthreads();
+            if (nsurv < tn) tn = nsurv;                           // what the compaction blocks will report (cap applies there)
+        }
+
+        const int gid = j * kBlock + threadIdx.x;                 // hypothesis (vi, hi) of image b
+        if (gid >= v.K * h.hn) return;
+        const int vi = gid / h.hn, hi = gid - vi * h.hn;
+        const size_t o = ((size_t)b * v.K + vi) * h.hn + hi;
+        h.counts[o] = 0;
+        if (tn <= 0) {
+            h.hyps[o] = make_float2(0.f, 0.f);
+            if (h.draws_out) { h.draws_out[2 * o] = -1; h.draws_out[2 * o + 1] = -1; }
+            return;
+        }
+        const bool first = hi < h.hn_first;
+        const int32_t *src = first ? h.idxs : h.idxs2;
+        int p0, p1;
+        if (src) {
+            const int32_t *ip = first ? h.idxs + (((size_t)b * h.hn_first + hi) * v.K + vi) * 2
+                                      : h.idxs2 + (((size_t)b * (h.hn - h.hn_first) + (hi - h.hn_first)) * v.K + vi) * 2;
+            int t0 = ip[0], t1 = ip[1];
+            // the reference reads out of bounds here; clamp instead of faulting
+            t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);
+            t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
+            p0 = select_pixel(s_prefix, a.T, img_lists, t0);
+            p1 = select_pixel(s_prefix, a.T, img_lists, t1);
+        } else {
+            const uint32_t stream = first ? h.stream : h.stream2;
+            const uint32_t c = (uint32_t)((first ? hi : hi - h.hn_first) * v.K + vi) * 2u;
+            const uint32_t img = (uint32_t)(a.b0 + b);
+            if (!sub) {
+                p0 = select_pixel(s_prefix, a.T, img_lists, (int)(rng_u32(a.seed, stream, img, c) % (uint32_t)tn));
+                p1 = select_pixel(s_prefix, a.T, img_lists, (int)(rng_u32(a.seed, stream, img, c + 1u) % (uint32_t)tn));
+            } else if (nsurv >= 0) {
+                const int *sv = h.surv + (size_t)b * kSurvCap;
+                p0 = sv[rng_u32(a.seed, stream, img, c) % (uint32_t)tn];
+                p1 = sv[rng_u32(a.seed, stream, img, c + 1u) % (uint32_t)tn];
+            } else {
+                p0 = p1 = -1;
+                for (int tr = 0; tr < kHypRejectTries && (p0 < 0 || p1 < 0); ++tr) {
+                    // try tr of draw c: key (stream + 16, image, c + tr * 2^24)  -- hn * K * 2 < 2^24 (validate())
+                    size_t e;
+                    if (p0 < 0) {
+                        const int p = select_pixel(s_prefix, a.T, img_lists,
+                                                   (int)(rng_u32(a.seed, stream + 16u, img, c + ((uint32_t)tr << 24)) % (uint32_t)total), &e);
+                        if (img_draws[e] < prob) p0 = p;
+                    }
+                    if (p1 < 0) {
+                        const int p = select_pixel(s_prefix, a.T, img_lists,
+                                                   (int)(rng_u32(a.seed, stream + 16u, img, c + 1u + ((uint32_t)tr << 24)) % (uint32_t)total), &e);
+                        if (img_draws[e] < prob) p1 = p;
+                    }
+                }
+                if (p0 < 0 || p1 < 0) {                            // no survivor found (prob ~ 0): degenerate pair
+                    h.hyps[o] = make_float2(0.f, 0.f);
+                    if (h.draws_out) { h.draws_out[2 * o] = p0; h.draws_out[2 * o + 1] = p1; }
+                    return;
+                }
+            }
+        }
+        const int y0 = p0 / a.W, x0 = p0 - y0 * a.W, y1 = p1 / a.W, x1 = p1 - y1 * a.W;
+        const float2 d0 = load_vertex(v, b, y0, x0, vi), d1 = load_vertex(v, b, y1, x1, vi);
+        h.hyps[o] = hypothesis_exact(d0.x, d0.y, (float)x0, (float)y0, d1.x, d1.y, (float)x1, (float)y1);
+        if (h.draws_out) { h.draws_out[2 * o] = p0; h.draws_out[2 * o + 1] = p1; }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compaction block: rows of image b
+    const int s = blockIdx.x - h.blocks;
+    if (fg < (long long)a.min_num) {      // P:129-132 / P:211-216: image skipped
+        if (s == 0 && threadIdx.x == 0) {
+            tn_out[b] = 0;
+            if (a.tn_user) a.tn_user[b] = 0;
+        }
+        return;
+    }
+    const bool sub = a.fuse_sub && fg > (long long)a.max_num;
+    if (!sub) {
+        if (s == 0 && threadIdx.x == 0) {
+            tn_out[b] = tn;
+            if (a.tn_user) a.tn_user[b] = tn;
+        }
+        constexpr int kKp = 9;                                     // gathers of one row in flight (PVNet: K = 9 in one trip)
+        const int row0 = s * h.rows * kBlock;
+        for (int q = 0; q < h.rows; ++q) {
+            if (row0 + q * kBlock >= tn) break;                    // block-uniform
+            const int r = row0 + q * kBlock + threadIdx.x;
+            if (r >= tn) continue;
+            const int p = select_pixel(s_prefix, a.T, img_lists, r);
+            const int y = p / a.W, x = p - y * a.W;
+            coords[(size_t)b * a.cap + r] = make_float2((float)x, (float)y);
+            for (int v0 = 0; v0 < v.K; v0 += kKp) {
+                float2 d[kKp];
+#pragma unroll
+                for (int c = 0; c < kKp; ++c)
+                    d[c] = v0 + c < v.K ? load_vertex(v, b, y, x, v0 + c) : make_float2(0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < kKp; ++c)
+                    if (v0 + c < v.K) dirs[((size_t)b * v.K + v0 + c) * a.cap + r] = d[c];
+            }
+        }
+        return;
+    }
+
+    // P:135-138 / P:219-223 fused: tile-wise.  The draws are stored per list entry, so the survivors of the tiles before
+    // tile t are counted from them (each block walks the image's draws once, incrementally) and tile t's list is
+    // filtered; the block that meets the last tile reports tn.
+    const float prob = (float)a.max_num / (float)fg;
+    int before = 0, counted = 0;                                   // survivors of tiles [0, counted)
+    for (int t = s; t < a.T; t += h.row_blocks) {
+        const int nz = s_prefix[t] - (t ? s_prefix[t - 1] : 0);
+        if (nz == 0 && t != a.T - 1) continue;                     // block-uniform
+        int cnt = 0;
+        for (int i = counted; i < t; ++i) {
+            const int ni = s_prefix[i] - (i ? s_prefix[i - 1] : 0);
+            const float *di = img_draws + (size_t)i * kTile;
+            for (int e = threadIdx.x; e < ni; e += kBlock)
+                cnt += di[e] < prob ? 1 : 0;
+        }
+        __syncthreads();
+        before += block_sum(cnt, red);
+        counted = t;
+        __syncthreads();
+        const int tile_n = filter_tile_list(nz, prob, img_lists + (size_t)t * kTile, img_draws + (size_t)t * kTile, list, seg);
+        __syncthreads();
+        if (t == a.T - 1 && threadIdx.x == 0) {                    // the last tile knows the subsampled total
+            const int all = before + tile_n;
+            tn_out[b] = all < a.cap ? all : a.cap;
+            if (a.tn_user) a.tn_user[b] = tn_out[b];
+        }
+        const int room = a.cap - before;                           // rows left in the image's list
+        const int n = tile_n < room ? tile_n : (room > 0 ? room : 0);
+        for (int i = threadIdx.x; i < n; i += kBlock) {
+            const int p = t * kTile + list[i];
+            const int yy = p / a.W;
+            coords[(size_t)b * a.cap + before + i] = make_float2((float)(p - yy * a.W), (float)yy);
+        }
+        // n*K gathers of 8 bytes each; eight per thread in flight (all loads of a trip before its stores)
+        constexpr int kGather = 8;
+        const int total_g = n * v.K;
+        for (int i0 = threadIdx.x; i0 < total_g; i0 += kGather * kBlock) {
+            float2 d[kGather];
+            size_t row[kGather];
+#pragma unroll
+            for (int u = 0; u < kGather; ++u) {
+                const int i = i0 + u * kBlock;
+                d[u] = make_float2(0.f, 0.f);
+                row[u] = 0;
+                if (i < total_g) {
+                    const int vi = i / n, li = i - vi * n;         // consecutive threads -> consecutive rows
+                    const int p = t * kTile + list[li];
+                    const int yy = p / a.W;
+                    d[u] = load_vertex(v, b, yy, p - yy * a.W, vi);
+                    row[u] = ((size_t)b * v.K + vi) * a.cap + before + li;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kGather; ++u)
+                if (i0 + u * kBlock < total_g) dirs[row[u]] = d[u];
+        }
+        __syncthreads();                                           // list[] / seg[] are rewritten for the next tile
+    }
+}
