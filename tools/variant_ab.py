@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--per-group", type=int, default=10)
     ap.add_argument("--mode", default="count", choices=["count", "v3"],
                     help="count: re-launches of the inlier-count kernel; v3: whole pvv_ransac_voting_v3 calls")
+    ap.add_argument("--rotate", type=int, default=1, help="v3 mode: cycle over this many distinct device-resident batches (cold caches)")
     a = ap.parse_args()
     synth = _synth()
     cfg = dict(synth.CONFIGS[a.config])
@@ -57,6 +58,8 @@ def main():
     d = synth.make_batch(B, cfg["H"], cfg["W"], cfg["K"], device=dev,
                          **{k: v for k, v in cfg.items() if k not in ("B", "H", "W", "K", "hn")})
     mask, vertex = d["mask"], d["vertex"]
+    others = [synth.make_batch(B, cfg["H"], cfg["W"], cfg["K"], device=dev, seed=50 + i,
+                               **{k: v for k, v in cfg.items() if k not in ("B", "H", "W", "K", "hn")}) for i in range(a.rotate - 1)]
     st = capi.stream()
     runs = []
     for spec in a.libs:
@@ -103,11 +106,14 @@ def main():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        rot = [args] + [(ctypes.byref(p), capi.ptr(o["mask"]), capi.ptr(o["vertex"]), None, None, capi.ptr(ws), n, capi.ptr(out),
+                         capi.ptr(win), capi.ptr(tn), st) for o in others]
         runs.append(dict(path=spec, L=L, p=p, ws=ws, n=n, win=int(win.sum().item()), out=out.double().sum().item(), ms=[],
-                         args=args, keep=(out, win, tn)))
+                         args=args, rot=rot, k=0, keep=(out, win, tn)))
     def launch(r):
         if a.mode == "v3":
-            r["L"].pvv_ransac_voting_v3(*r["args"])
+            r["k"] += 1
+            r["L"].pvv_ransac_voting_v3(*r["rot"][r["k"] % len(r["rot"])])
         else:
             r["L"].pvv_rerun_count_kernel(ctypes.byref(r["p"]), capi.ptr(r["ws"]), r["n"], 0, st)
 
