@@ -23,6 +23,7 @@ import torch  # noqa: E402
 ROWS = [
     # name, config, B, overrides
     ("cfg2_B1", "cfg2", 1, {}),
+    ("cfg2_dense_tn30000_B1", "cfg2", 1, {"fg": 0.0985}),      # the dense stress of config 2 (tn ~ 30000)
     ("cfg3_B2", "cfg3", 2, {}),
     ("cfg3_B4", "cfg3", 4, {}),
     ("cfg3_B8_shard_of_8gpu", "cfg3", 8, {}),
@@ -65,6 +66,8 @@ def main():
         hn = over.get("hn", cfg["hn"])
         max_num = over.get("max_num", 30000)
         gen = {k: v for k, v in cfg.items() if k not in ("B", "hn")}
+        if "fg" in over:
+            gen["fg"] = over["fg"]
         d = synth.make_batch(B=B, **gen, device=dev)
         mask, vertex = d["mask"], d["vertex"]
         n = args.calls if B <= 16 else max(20, args.calls // 4)
