@@ -64,6 +64,8 @@ def main():
                          "step 8, 0.300 at step 30, 0.279 from step 60 on -- so a 25-step run would time the ramp, not the path")
     ap.add_argument("--config", default="cfg3", help="image shape / K / hn / foreground of this BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-stream", action="store_true",
+                    help="N = 1: skip the two-stream extra (profiling runs: overlapped launches would blur per-kernel durations)")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the weak-scaling and overlapped variants")
     ap.add_argument("--extras", action="store_true",
                     help="also time config 2 (B=1 latency) and v3+estimate; off by default so that a rocprofv3 "
@@ -173,7 +175,7 @@ def main():
     # batches would issue them -- the scan / compaction of step i+1 run under the (VALU-bound) count kernel of step i.
     # Splitting ONE call over streams loses instead (tools/two_stream.py), so the library does not do that by itself.
     two_stream = None
-    if not use_dist and B > 0:
+    if not use_dist and B > 0 and not args.no_two_stream:
         side = [torch.cuda.Stream(), torch.cuda.Stream()]
         def alternating_step(i):
             with torch.cuda.stream(side[i & 1]):

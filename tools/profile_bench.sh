@@ -6,7 +6,7 @@ TAG=${1:-run}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="python $PWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-two-stream"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/bench_trace.log 2>&1
 # separate counter passes (never combined with tracing domains)
