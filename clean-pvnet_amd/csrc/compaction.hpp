@@ -126,7 +126,7 @@ template <> struct RawElem<2> { typedef uint16_t type; };
 template <> struct RawElem<4> { typedef uint32_t type; };
 template <> struct RawElem<8> { typedef uint64_t type; };
 
-template <int ES>
+template <int ES, bool AHEAD>
 __global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__restrict__ tiles,
                                                       unsigned short *__restrict__ tile_list,
                                                       float *__restrict__ tile_draw, int total_tiles)
@@ -135,10 +135,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__re
     __shared__ int seg2[2][kTileSteps * 4 + 1];                    // double-buffered by the parity of the iteration: the
     __shared__ int red2[2][4];                                     // next tile's counts are written while stragglers still read
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const bool ahead = a.contig && !a.seg;
-    raw_t cur[kTileSteps] = {};
+    constexpr bool ahead = AHEAD;                                  // host: a.contig && !a.seg
+    raw_t cur[AHEAD ? kTileSteps : 1] = {};
     int g = blockIdx.x;
-    if (ahead && g < total_tiles) {
+    if constexpr (AHEAD) if (g < total_tiles) {
         const int b = g / a.T, t = g - b * a.T;
         const raw_t *src = (const raw_t *)a.mask + (int64_t)b * a.sb + (int64_t)t * kTile;
 #pragma unroll
@@ -150,9 +150,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__re
     for (int it = 0; g < total_tiles; g += gridDim.x, ++it) {
         const int b = g / a.T, t = g - b * a.T;
         int *seg = seg2[it & 1], *red = red2[it & 1];
-        raw_t nxt[kTileSteps] = {};
+        raw_t nxt[AHEAD ? kTileSteps : 1] = {};
         const int gn = g + gridDim.x;
-        if (ahead && gn < total_tiles) {
+        if constexpr (AHEAD) if (gn < total_tiles) {
             const int bn = gn / a.T, tn = gn - bn * a.T;
             const raw_t *src = (const raw_t *)a.mask + (int64_t)bn * a.sb + (int64_t)tn * kTile;
 #pragma unroll
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__re
         for (int s = 0; s < kTileSteps; ++s) {
             const int p = t * kTile + s * kBlock + threadIdx.x;
             int w = 0;
-            if (ahead) {
+            if constexpr (AHEAD) {
                 const uint64_t v = (uint64_t)cur[s];               // 0 beyond the image
                 w = a.mode == 0 ? (int)(v & 0xFF) : (v == 1 ? 1 : 0);
             } else if (p < a.HW) {
@@ -191,8 +191,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__re
                 list[r] = (unsigned short)(s * kBlock + threadIdx.x);
                 if (a.want_draws) draw[r] = selection_draw(a, b, t * kTile + s * kBlock + threadIdx.x);
             }
+        if constexpr (AHEAD) {
 #pragma unroll
-        for (int s = 0; s < kTileSteps; ++s) cur[s] = nxt[s];
+            for (int s = 0; s < kTileSteps; ++s) cur[s] = nxt[s];
+        }
     }
 }
 

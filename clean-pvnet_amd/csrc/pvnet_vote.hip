@@ -254,22 +254,29 @@ int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_
 template <int ES>
 void launch_scan(const MaskArgs &m, const Layout &L, char *ws, int B, hipStream_t st)
 {
-    // persistent over the B*T tiles: as many blocks as the chip holds at once (8 per CU), every block the same number of
-    // tiles (+-1)
     const long long total = (long long)L.T * B;
+    uint32_t *tiles = (uint32_t *)(ws + L.tiles);
+    unsigned short *lists = (unsigned short *)(ws + L.tile_list);
+    float *draws = (float *)(ws + L.tile_draw);
+    // the read-ahead needs a contiguous mask; a strided mask or the fused argmax keep one short-lived block per tile
+    // (their loads are not issued ahead, and a persistent block would walk its tiles one load latency at a time)
+    if (!(m.contig && !m.seg)) {
+        hipLaunchKernelGGL((k_tile_scan<ES, false>), dim3((unsigned)total), dim3(kBlock), 0, st, m, tiles, lists, draws, (int)total);
+        return;
+    }
+    // persistent over the B*T tiles: as many blocks as the chip holds at once, every block the same number of tiles (+-1)
     static int per_cu[64] = {0};                                    // resident blocks per CU of this instantiation, per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!per_cu[dev]) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile_scan<ES>, kBlock, 0) != hipSuccess || n < 1) n = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile_scan<ES, true>, kBlock, 0) != hipSuccess || n < 1) n = 4;
         per_cu[dev] = n > 8 ? 8 : n;
     }
     const long long resident = (long long)per_cu[dev] * num_cus();
     const long long per_block = (total + resident - 1) / resident;
     const int grid = (int)((total + per_block - 1) / per_block);
-    hipLaunchKernelGGL(k_tile_scan<ES>, dim3(grid), dim3(kBlock), 0, st, m, (uint32_t *)(ws + L.tiles),
-                       (unsigned short *)(ws + L.tile_list), (float *)(ws + L.tile_draw), (int)total);
+    hipLaunchKernelGGL((k_tile_scan<ES, true>), dim3(grid), dim3(kBlock), 0, st, m, tiles, lists, draws, (int)total);
 }
 
 struct Front {

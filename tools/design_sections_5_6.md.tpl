@@ -29,14 +29,16 @@
   2.4 GHz (the profiled box ran the kernel at 2.39 GHz); the rest is prologues, flagged tiles (9 % at B = 64, 17 % at
   B = 8: `tools/band_cost.sh`) and the ends of the kernel (`SQ_ACTIVE_INST_VALU`: 97 % busy, `profiles/r02_summary.json`).
 * Round-2 numbers (MI355X, `profiles/r02_*`, one box, rotating batches): **{{v}} k images/s** at B = 64
-  ({{ms}} ms/step wall, {{med}} median, p10/p90 {{p10}}/{{p90}}); count kernel {{k}} ms by HIP events (0.1829 ms in the
-  process that `rocprofv3 --kernel-trace --stats` profiled, whose own average over all 514 launches — ramp included — is
-  0.1899 ms: `r02_bench_under_rocprof.json`, `r02_kernel_stats.csv`) ⇒ **{{frac}} % of the HBM roofline** (target ≥ 40 %).
+  ({{ms}} ms/step wall, {{med}} median, p10/p90 {{p10}}/{{p90}}); count kernel {{k}} ms by HIP events ({{k_under}} ms in the
+  process that `rocprofv3 --kernel-trace --stats` profiled, whose own average over all {{calls}} launches — ramp included — is
+  {{k_stats}} ms: `r02_bench_under_rocprof.json`, `r02_kernel_stats.csv`) ⇒ **{{frac}} % of the HBM roofline** (target ≥ 40 %).
   The kernel is timed after the same clock pre-warm as the steps: measured right after an idle moment it read 0.217 ms
   on the same box (and that is what round 1's 0.2232 ms was).  Per call in the profiled run (cold inputs):
-  `k_tile_scan` 39.1 µs, `k_compact_hyp` 33.5, `k_count_bf16` 189.9, `k_select_refit` 14.1, `k_finalize_v3` 4.8; replaying
-  one warm batch without pre-warm (`profiles/r02_gaps_cfg3_B64.json`): 30.7 + 28.4 + 201.2 + 14.4 + 4.8 = 280 µs (round 1,
-  same protocol: 28.8 + 24.5 + 11.7 + 218.9 + 15.2 + 4.6 = 304 µs).  Extras
+  `k_tile_scan` {{cold_scan}} µs (39.1 before it became persistent with read-ahead), `k_compact_hyp` {{cold_k2}}, `k_count_bf16` {{cold_count}},
+  `k_select_refit` {{cold_refit}}, `k_finalize_v3` {{cold_fin}}; replaying one warm batch without pre-warm
+  (`profiles/r02_gaps_cfg3_B64.json`): {{warm}} µs (round 1, same protocol: 28.8 + 24.5 + 11.7 + 218.9 + 15.2 + 4.6 =
+  304 µs).  The same steps alternating over two streams, as a caller decoding a sequence of batches can issue them
+  (`extra.two_stream_images_per_s`, never `value`): **{{ts}} k images/s**.  Extras
   (`r02_bench_extras.json`): B = 1 latency {{b1}} µs/call (round 1: 38); v3 + estimate (4096 hypotheses) {{est}} k images/s;
   fused `decode_keypoint` {{df}} k vs {{du}} k images/s for `torch.argmax` + v3; un_pnp one pass {{one}} k vs {{two}} k; the
   reference's default non-`un_pnp` call {{dp}} k images/s (round 1: 769 k).  Host-buffer note: the boundary takes device
@@ -83,7 +85,7 @@ What has executed on hardware (one GPU is all `gpurun` gives): a real RCCL proce
 torch.distributed.run --nproc-per-node 1 … bench.py --gpus 1`: `init_process_group("nccl", device_id=…)`, an
 `all_gather_into_tensor` in every step, barrier + max-over-ranks timing; `rccl_ranks` in the JSON comes from the
 collective's own result) and runs the HIP layer under `sharded_vote` in a one-rank `nccl` group against the un-sharded
-call (`profiles/r02_bench_torchrun_1rank.json`: 0.2871 vs 0.2757 ms/step without the group).  No scaling curve could be
+call (`profiles/r02_bench_torchrun_1rank.json`: {{tr_ms}} vs {{ms}} ms/step without the group).  No scaling curve could be
 measured here.  **Expectation for the driver's strong-scaling run of config 3** from the single-GPU shard timings above:
 64 images take 0.265 ms on one GPU; a shard of 8 takes 0.070 ms (+ the ≈10–30 µs exchange) ⇒ speed-up ≈ 3.0–3.3× on
 8 GPUs, efficiency ≈ 40 %, because a shard of 8 images is latency-bound (§5): near-linear *weak* scaling (64 images per

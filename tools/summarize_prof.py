@@ -42,7 +42,10 @@ def main():
         print("pmc", s)
         for c, v in sorted(pmc[s].items()):
             v = sorted(v)
-            big = [x for x in v if x > 0.5 * v[-1]] or v
+            # the launches of the bench batch: within a factor two of the 90th percentile (one outlier -- a launch that
+            # shared the chip with something else -- must not define the scale, as a plain "> max / 2" did)
+            ref = v[min(len(v) - 1, int(0.9 * len(v)))]
+            big = [x for x in v if 0.5 * ref < x < 2.0 * ref] or v
             print("    %-22s n=%4d  max=%.4g  main-mean=%.4g" % (c, len(v), v[-1], sum(big) / len(big)))
             out.setdefault("pmc", {}).setdefault(s, {})[c] = dict(n=len(v), max=v[-1], main_mean=sum(big) / len(big))
     if "--json" in sys.argv:
