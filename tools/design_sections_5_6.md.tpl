@@ -7,8 +7,8 @@
   shards of 64/N (`"scaling": "strong"`); the weak figure (64 per GPU) and the variant that overlaps the exchange with the
   next step are in `extra`.  `--extras` adds config 2 (B = 1 latency), v3+estimate, the default path, `decode_keypoint`.
 * Protocol (SURVEY §8(d), VERDICT r1 #3): steps cycle over **3 distinct device-resident batches** (4.7 GB: neither the
-  256 MiB Infinity Cache nor L2 holds a step's inputs from the step before — the mask scan then runs at 4.0 instead of
-  5.3 TB/s and the step costs ≈ +15 µs against replaying one batch); **per-step HIP events** on the launch stream →
+  256 MiB Infinity Cache nor L2 holds a step's inputs from the step before — the mask scan then runs at 4.4 instead of
+  5.2 TB/s and the step costs ≈ +10 µs against replaying one batch); **per-step HIP events** on the launch stream →
   `step_ms` median / p10 / p90 beside the contract's wall-clock `ms_per_step`; a disclosed **clock pre-warm** (60 ms of
   untimed steps before the W warm-up steps): after the GPU-idle data generation the chip needs ≈60 steps to reach steady
   clocks (`tools/clock_ramp.py`: 0.335 ms/step at step 8, 0.300 at step 30, 0.279 from step 60 on), so a 25-step run
