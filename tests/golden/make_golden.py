@@ -163,8 +163,48 @@ def main():
     cases["estimate_basic"] = dict(mask=mask, vertex=vertex, idxs=idxs, mean=mean, round_hyp_num=64, min_hyp_num=256,
                                    thresh=np.float32(0.99), cov=cov.numpy())
 
+    # ---- v3 on a uint8 mask of 255s: foreground_num is the SUM of the byte values (:126), so ~740 pixels count as
+    #      ~189 000 > max_num and are subsampled with probability max_num / (255 * pixels) (:135-138)
+    torch.manual_seed(123)
+    mask, vertex, kpt = field(9, 96, 128, 4, 0.06, 0.03)
+    mask = (mask * 255).astype(np.uint8)
+    state = torch.get_rng_state()
+    recorded.clear()
+    # (.byte() of a uint8 tensor is the tensor itself, so the reference's `cur_mask *= selected_mask` (:138) would
+    #  subsample the CALLER's mask in place: hand it a copy)
+    out = ref.ransac_voting_layer_v3(torch.from_numpy(mask[None].copy()), torch.from_numpy(vertex[None]), 64, inlier_thresh=0.99)
+    torch.set_rng_state(state)
+    selection = torch.zeros(mask.shape, dtype=torch.float32).uniform_(0, 1).numpy()
+    assert int(mask.astype(np.int64).sum()) > 30000 and recorded[0].max() < 400
+    cases["v3_bytemask"] = dict(mask=mask[None], vertex=vertex[None], idxs=recorded[0][None], hn=64, thresh=np.float32(0.99),
+                                out=out.numpy(), selection=selection[None], max_num=30000, kpt=kpt[None])
+
+    # ---- estimate with max_num subsampling (:219-223): foreground = count of (mask == 1), one uniform_ draw per image
+    torch.manual_seed(321)
+    mask, vertex, kpt = field(10, 96, 128, 4, 0.2, 0.03)
+    max_num = 900
+    assert int((mask == 1).sum()) > max_num
+    mean = (kpt[None] + 0.25).astype(np.float32)
+    state = torch.get_rng_state()
+    recorded.clear()
+    rmean, cov = ref.estimate_voting_distribution_with_mean(torch.from_numpy(mask[None].copy()), torch.from_numpy(vertex[None]),
+                                                            torch.from_numpy(mean), round_hyp_num=64, min_hyp_num=128,
+                                                            max_num=max_num)
+    torch.set_rng_state(state)
+    selection = torch.zeros(mask.shape, dtype=torch.float32).uniform_(0, 1).numpy()
+    assert len(recorded) == 2
+    cases["estimate_subsample"] = dict(mask=mask[None], vertex=vertex[None], idxs=np.concatenate(recorded, 0)[None], mean=mean,
+                                       round_hyp_num=64, min_hyp_num=128, max_num=max_num, selection=selection[None],
+                                       thresh=np.float32(0.99), cov=cov.numpy())
+
     for name, c in cases.items():
-        np.savez_compressed(os.path.join(OUT, name + ".npz"), **c)
+        path = os.path.join(OUT, name + ".npz")
+        if os.path.exists(path) and "--force" not in sys.argv:       # committed fixtures are not rewritten (zip metadata churn)
+            old = dict(np.load(path))
+            same = all(np.array_equal(np.asarray(old[k]), np.asarray(v)) for k, v in c.items()) and set(old) == set(c)
+            print(name, "exists,", "identical content" if same else "CONTENT DIFFERS (run with --force to rewrite)")
+            continue
+        np.savez_compressed(path, **c)
         print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in c.items()})
 
 

@@ -41,6 +41,28 @@ def test_v3_subsample(oracle, pkg, gpu):
     assert np.abs(c["out"] - exact).max() > 1e-4        # the fixture where the reference's own rounding exceeds the contract
 
 
+def test_v3_bytemask(oracle, pkg, gpu):
+    """uint8 mask of 255s: foreground_num = sum of the byte values (P:126) decides the subsampling (P:135-138)."""
+    from clean_pvnet_amd.ransac_voting_gpu import ransac_voting_layer_v3
+    c, t = gold("v3_bytemask", gpu)
+    out = ransac_voting_layer_v3(t["mask"], t["vertex"], int(c["hn"]), inlier_thresh=float(c["thresh"]),
+                                 max_num=int(c["max_num"]), idxs=t["idxs"], selection=t["selection"])
+    exact = tol.exact_v3(oracle, c["mask"], c["vertex"], int(c["hn"]), float(c["thresh"]), c["idxs"], selection=c["selection"],
+                         max_num=int(c["max_num"]))
+    tol.assert_means_close(out.cpu().numpy(), exact)
+    tol.assert_means_close(out.cpu().numpy(), c["out"], extra=np.abs(c["out"] - exact))
+    assert t["mask"].max().item() == 255            # the input is not subsampled in place (the reference does that to a uint8 mask)
+
+
+def test_estimate_subsample(pkg, gpu):
+    from clean_pvnet_amd.ransac_voting_gpu import estimate_voting_distribution_with_mean
+    c, t = gold("estimate_subsample", gpu)
+    mean, cov = estimate_voting_distribution_with_mean(t["mask"], t["vertex"], t["mean"], int(c["round_hyp_num"]),
+                                                       int(c["min_hyp_num"]), max_num=int(c["max_num"]), idxs=t["idxs"],
+                                                       selection=t["selection"])
+    tol.assert_cov_close(cov.cpu().numpy(), c["cov"], rtol=tol.COV_RTOL_VS_REFERENCE_F32, what="cov vs the reference's float32 glue")
+
+
 def test_v3_singular_reference_policy_is_default(oracle, pkg, gpu):
     from clean_pvnet_amd.ransac_voting_gpu import ransac_voting_layer_v3
     c, t = gold("v3_singular", gpu)

@@ -99,6 +99,30 @@ def test_golden_v3_subsample_matches_reference_glue(oracle):
     tol.assert_means_close(out, c["out"], extra=np.abs(c["out"] - exact))
 
 
+def test_golden_v3_bytemask_weight_sum_subsampling(oracle):
+    """A uint8 mask of 255s through the reference's glue: foreground_num sums the byte VALUES (:126), so 738 pixels are
+    subsampled as if they were 188 190 (:135-138); the recorded index pairs address the ~110 survivors."""
+    c = gold("v3_bytemask")
+    assert c["mask"].dtype == np.uint8 and int(c["mask"].max()) == 255
+    det = []
+    kw = dict(selection=c["selection"], max_num=int(c["max_num"]))
+    out = oracle.ransac_voting_layer_v3(c["mask"], c["vertex"], int(c["hn"]), float(c["thresh"]), idxs=c["idxs"], details=det, **kw)
+    assert 60 < det[0]["tn"] < 200 and int(c["idxs"].max()) < det[0]["tn"]
+    exact = tol.exact_v3(oracle, c["mask"], c["vertex"], int(c["hn"]), float(c["thresh"]), c["idxs"], **kw)
+    tol.assert_means_close(out, exact)
+    tol.assert_means_close(out, c["out"], extra=np.abs(c["out"] - exact))
+
+
+def test_golden_estimate_subsample_matches_reference_glue(oracle):
+    c = gold("estimate_subsample")
+    det = []
+    _m, cov = oracle.estimate_voting_distribution_with_mean(c["mask"], c["vertex"], c["mean"], int(c["round_hyp_num"]),
+                                                            int(c["min_hyp_num"]), max_num=int(c["max_num"]), idxs=c["idxs"],
+                                                            selection=c["selection"], details=det)
+    assert 700 < det[0]["tn"] < 1100 and int((c["mask"] == 1).sum()) > int(c["max_num"])
+    tol.assert_cov_close(cov, c["cov"], rtol=tol.COV_RTOL_VS_REFERENCE_F32, what="cov vs the reference's float32 glue")
+
+
 def test_fp64_refit_is_the_one_closer_to_the_exact_solution(oracle):
     """on v3_subsample the oracle (binary64 normal equations, what the product does too) and the
     reference's glue (binary32, torch.matmul) differ by 1.8e-4 px -- more than the 1e-4 contract.  Against the EXACT
