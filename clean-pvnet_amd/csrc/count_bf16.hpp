@@ -139,8 +139,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         int nhg = (nt + htpi - 1) / htpi;
         int gpi = nhg;                                              // groups per item
         while (gpi > 1 && chunks * ((nhg + gpi - 1) / gpi) < target_items) gpi = (gpi + 1) >> 1;
+        // groups below 4 tiles only for very small problems (< 128 (chunk, keypoint) pairs: every item they add is another
+        // CU put to work); otherwise the prologue of an item is worth more than the 16 matrix-core tiles of a 2-tile group
+        const int htpi_min = chunks < 128 ? 2 : 4;
         if (gpi == 1)
-            while (htpi > 2 && chunks * ((nt + htpi - 1) / htpi) < target_items) htpi = (htpi + 1) >> 1;
+            while (htpi > htpi_min && chunks * ((nt + htpi - 1) / htpi) < target_items) htpi = (htpi + 1) >> 1;
         if (lane == 0) { s_htpi = htpi; s_gpi = gpi; s_chunks = carry; }
     }
     __syncthreads();

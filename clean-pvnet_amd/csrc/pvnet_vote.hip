@@ -211,11 +211,15 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     // block the same NUMBER of items was 6 % slower too -- its stride (32 images' worth of items) lines the near-empty
     // last chunks of all images up in the same blocks.
     const int per_cu_t = tuning_int("PVV_GRID_PER_CU", 0);
-    const int items_per_cu = tuning_int("PVV_ITEMS_PER_CU", 2);
-    // Small batches (every item fits the 5 resident blocks per CU): exactly one generation of blocks -- a block
-    // without an item still costs ~1 us (it has to read tn[] to find that out), and three generations of them kept
-    // the kernel alive 2 us after the last working block at B = 1.
-    const int per_cu = per_cu_t > 0 ? per_cu_t : (p->B <= 8 ? 5 : (p->hn <= 512 ? 15 : 48));
+    // Item size: the kernel splits (chunk, keypoint) pairs into runs / groups of hypothesis tiles until there are at least
+    // 5 items per CU (round-2 sweep, tools/sweep_count.py: against 2 per CU -12 % at B = 8, -8 % at B = 4, -20 % for the
+    // 4096-hypothesis estimate at B <= 8, +-0 from B = 24 on).
+    const int items_per_cu = tuning_int("PVV_ITEMS_PER_CU", 5);
+    // Grid: up to ~2000 items one generation of blocks (the 5 resident ones per CU, a few of them take two items) -- a
+    // block without an item still costs ~1 us (it has to read tn[] to find that out), and three generations of them kept
+    // the kernel alive 2 us after the last working block at B = 1; 15 per CU lose 6 % at B = 16 and win 8 % at B = 24.
+    // The host does not know tn, so the batch size stands in for the item count.
+    const int per_cu = per_cu_t > 0 ? per_cu_t : (p->B <= 16 ? 5 : (p->hn <= 512 ? 15 : 48));
     hipLaunchKernelGGL(k_count_bf16, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, (const float2 *)(ws + L.coords),
                        (const float2 *)(ws + L.dirs), (const float2 *)(ws + L.hyps), (int *)(ws + L.counts),
                        (const int *)(ws + L.tn), p->B, p->K, p->hn, p->cap, p->inlier_thresh,
