@@ -157,7 +157,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     const int col = lane & 31, kslice = lane >> 5;
     PVV_STAMP(2);
 
-    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    // The host sizes the grid without knowing tn.  With few items (up to 7/4 of the one-generation grid = target_items)
+    // only the first target_items blocks of a 15-per-CU grid take part -- one generation, a few blocks with two items,
+    // measured faster than spreading them over three generations (B = 16: 54.9 vs 57.9 us) -- and the others leave here
+    // (they pass through the slots the working blocks free: no measurable tail).  With many items every block works
+    // (config 5 at B = 16: 1.43 vs 1.70 ms), and so does the 48-per-CU grid of the long-hypothesis configurations
+    // (11 000 leaving blocks would be a tail: +10 % on config 4 at B = 16).
+    const int nblk = (total <= target_items + (target_items >> 1) + (target_items >> 2) && (int)gridDim.x > target_items &&
+                      (int)gridDim.x <= 3 * target_items) ? target_items : (int)gridDim.x;
+    if ((int)blockIdx.x >= nblk) return;
+    for (int item = blockIdx.x; item < total; item += nblk) {
         const int gchunk = item / per_chunk;                    // chunk index over the whole batch
         const int rem = item - gchunk * per_chunk;
         int local;

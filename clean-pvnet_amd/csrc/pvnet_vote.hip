@@ -218,8 +218,9 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     // Grid: up to ~2000 items one generation of blocks (the 5 resident ones per CU, a few of them take two items) -- a
     // block without an item still costs ~1 us (it has to read tn[] to find that out), and three generations of them kept
     // the kernel alive 2 us after the last working block at B = 1; 15 per CU lose 6 % at B = 16 and win 8 % at B = 24.
-    // The host does not know tn, so the batch size stands in for the item count.
-    const int per_cu = per_cu_t > 0 ? per_cu_t : (p->B <= 16 ? 5 : (p->hn <= 512 ? 15 : 48));
+    // The host does not know tn: up to B = 8 it launches the one generation, beyond that 15 per CU (48 for >= 2048
+    // hypotheses: long, uneven items) and the KERNEL falls back to one generation when it finds few items (count_bf16.hpp).
+    const int per_cu = per_cu_t > 0 ? per_cu_t : (p->B <= 8 ? 5 : (p->hn < 2048 ? 15 : 48));
     hipLaunchKernelGGL(k_count_bf16, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, (const float2 *)(ws + L.coords),
                        (const float2 *)(ws + L.dirs), (const float2 *)(ws + L.hyps), (int *)(ws + L.counts),
                        (const int *)(ws + L.tn), p->B, p->K, p->hn, p->cap, p->inlier_thresh,
