@@ -53,13 +53,12 @@
   each + tensor allocation), so below B ≈ 2 the eager wall clock is host-bound; a captured graph removes that (the
   replay column: the GPU side is what remains).  Per-kernel at B = 1 (`r02_gaps_cfg2_B1.json`): scan 5.4, compact +
   hypotheses 7.2, count 12.8, refit 5.2, finalize 4.0 µs.  **The small-batch targets of VERDICT r1 #1 (B = 1 ≤ 20 µs,
-  B = 8 ≤ 45 µs, default path ≥ 1.5 M images/s) are NOT met**: B = 1 went 40.3 → 35 µs, B = 8 stayed at 70 µs (the count
-  kernel gained 1–3 µs, the merged front end about as much, both within the box-to-box spread), the default path went
-  730 k → 945 k images/s.  What was learned trying (§4.4, §4.5): a kernel boundary costs 1.45 µs, but every *dependent
+  B = 8 ≤ 45 µs, default path ≥ 1.5 M images/s) are NOT met**: B = 1 went 40.3 → 34 µs, B = 8 70 → 64 µs (the item-size sweep of
+  §4.4 took 5 µs off its count kernel, the merged front end 1–3 µs), the default path went 730 k → 900–950 k images/s.  What was learned trying (§4.4, §4.5): a kernel boundary costs 1.45 µs, but every *dependent
   phase* — barrier + memory round trip — costs 2.5–5 µs whether it is its own launch or a phase of a fused kernel
   (tickets, in-kernel hand-offs and a fully fused back end were built, are bit-exact, and are not faster); the path has
   five such phases between the mask and the keypoints (scan → prefix/compaction → counts → arg-max + refit → policy over
-  the keypoints), and at B = 8 the count kernel's 900 work items quantise to 3 or 4 per CU.
+  the keypoints), and a shard of 8 images is a third of one generation of the count kernel's work items.
 * The reference's own kernel on the same GPU (`oracle/_ref`, `tests/test_ref_pin.py::test_reference_kernel_timed_on_the_same_gpu`):
   `voting_for_hypothesis_kernel` + `torch.sum` for ONE 480×640 image (K = 9, 512 hypotheses, what P:155-159 runs per
   image and round) takes 0.21 ms on the MI355X, i.e. 13 ms for the 64 images that `k_count_bf16` counts in 0.2 ms
@@ -87,8 +86,8 @@ torch.distributed.run --nproc-per-node 1 … bench.py --gpus 1`: `init_process_g
 collective's own result) and runs the HIP layer under `sharded_vote` in a one-rank `nccl` group against the un-sharded
 call (`profiles/r02_bench_torchrun_1rank.json`: {{tr_ms}} vs {{ms}} ms/step without the group).  No scaling curve could be
 measured here.  **Expectation for the driver's strong-scaling run of config 3** from the single-GPU shard timings above:
-64 images take 0.265 ms on one GPU; a shard of 8 takes 0.070 ms (+ the ≈10–30 µs exchange) ⇒ speed-up ≈ 3.0–3.3× on
-8 GPUs, efficiency ≈ 40 %, because a shard of 8 images is latency-bound (§5): near-linear *weak* scaling (64 images per
+64 images take 0.271 ms on one GPU; a shard of 8 takes 0.064 ms (+ the ≈10–30 µs exchange) ⇒ speed-up ≈ 3.0–3.6× on
+8 GPUs, efficiency ≈ 40–45 %, because a shard of 8 images is latency-bound (§5): near-linear *weak* scaling (64 images per
 GPU: the exchange is the only addition), not near-linear strong scaling at this problem size.  `num_cus()` is per
 device now.
 
