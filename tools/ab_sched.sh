@@ -1,3 +1,5 @@
+# Whole-call A/B (cold batches, one process) of scheduling variants of the count kernel: build them with
+# tools/build_variant.sh, list them in run(), then   gpurun -- "bash tools/ab_sched.sh"
 run() { python tools/variant_ab.py build/variants/sched.so build/variants/devE.so --mode v3 --rotate 2 --rounds $1 --batch $2 --config $3 | python -c "
 import sys,json
 r=[json.loads(l) for l in sys.stdin]; print('$3 B',r[0]['B'],[(x['lib'][:-3],x['ms_mean'],x['ratio']) for x in r], len(set(x['out_sum'] for x in r))==1)"; }
