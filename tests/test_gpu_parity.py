@@ -957,6 +957,30 @@ def test_randomized_soak_all_counts_bit_exact(oracle, synth, pkg, gpu, case):
     tol.assert_means_close(_np(out), want)
 
 
+@pytest.mark.parametrize("dtype", [torch.int64, torch.uint8])
+def test_strided_mask_views_equal_the_contiguous_mask(synth, pkg, gpu, dtype):
+    """The mask is taken by strides (pvv_problem.mask_stride), not copied: a view with a padded row pitch, a channel slice of
+    a [B,2,H,W] tensor and an every-other-column view give the results of their contiguous copies (same seed; the
+    read-ahead scan is for contiguous masks only, these take the one-block-per-tile instantiation)."""
+    from clean_pvnet_amd.ransac_voting_gpu import estimate_voting_distribution_with_mean, ransac_voting_layer_v3
+    d = synth.make_batch(B=3, H=96, W=160, K=5, fg=0.08, sigma=0.03, seed=21, device=gpu, mask_dtype=dtype)
+    mask, vertex = d["mask"], d["vertex"]
+    B, H, W = mask.shape
+    padded = torch.zeros(B, H, W + 7, dtype=dtype, device=gpu)
+    padded[:, :, 3:3 + W] = mask
+    two = torch.stack([1 - mask.clamp(max=1), mask], 1)                   # [B,2,H,W]
+    wide = torch.zeros(B, H, 2 * W, dtype=dtype, device=gpu)
+    wide[:, :, ::2] = mask
+    views = [padded[:, :, 3:3 + W], two[:, 1], wide[:, :, ::2]]
+    want = ransac_voting_layer_v3(mask, vertex, 128, inlier_thresh=0.99, seed=9)
+    want_cov = estimate_voting_distribution_with_mean(mask, vertex, want, 64, 256, seed=9)[1]
+    for v in views:
+        assert not v.is_contiguous() and torch.equal(v, mask)
+        got = ransac_voting_layer_v3(v, vertex, 128, inlier_thresh=0.99, seed=9)
+        assert torch.equal(got, want)
+        assert torch.equal(estimate_voting_distribution_with_mean(v, vertex, got, 64, 256, seed=9)[1], want_cov)
+
+
 def test_calls_on_two_streams_are_independent(synth, pkg, gpu):
     """The library launches on the caller's stream and owns no global state: calls enqueued on two streams at once (each
     with its own workspace, as the shim allocates them) give the results of the same calls made one after the other."""
