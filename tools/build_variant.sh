@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build an experimental copy of libpvnet_vote.so into build/variants/<name>.so from a patched scratch copy of csrc/
-# (the product sources stay untouched).  usage: tools/build_variant.sh <name> [-e sed-expr]... [--py edit.py] [-Dmacro]...
+# (the product sources stay untouched).  usage: tools/build_variant.sh <name> [-e sed-expr]... [--py edit.py] [-Dmacro]... [-X "extra flags"]...
 #   tools/build_variant.sh base
 #   tools/build_variant.sh nohot -e 's/ht < nht; ++ht) {\s*$/ht < 0; ++ht) {/'
 set -e
@@ -13,6 +13,7 @@ while [ $# -gt 0 ]; do
   case "$1" in
     -e) sedargs+=(-e "$2"); shift 2;;
     -D*) defs+=("$1"); shift;;
+    -X) defs+=($2); shift 2;;                    # extra compiler flags, e.g. -X "-mllvm -amdgpu-sched-strategy=max-ilp"
     --py) python "$2" "$scratch"; shift 2;;      # a python script that edits the scratch copy in place
     *) echo "unknown arg $1"; exit 1;;
   esac
