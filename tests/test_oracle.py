@@ -169,6 +169,21 @@ def test_golden_estimate_matches_reference_glue(oracle):
     assert np.abs(c["cov"][1]).max() > 100                      # skipped image: hyps = 0, ratios = 1 -> mean mean^T
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/lib/csrc/ransac_voting/ransac_voting_gpu.py"),
+                    reason="the reference tree exists only in the build container")
+def test_golden_fixtures_are_reproducible_from_the_reference():
+    """tests/golden/make_golden.py, run here against the reference where it lies, regenerates every committed fixture
+    with identical content (it never rewrites an existing file without --force)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_golden.py")], cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if " exists," in l]
+    assert len(lines) == 7 and all(l.endswith("identical content") for l in lines), out.stdout
+
+
 # ---------------------------------------------------------------------------------- known answers / properties
 def test_known_answer_clean_field(oracle, synth):
     """compute_vertex semantics (pvnet_data_utils.py:30-44) without noise: voting returns the keypoints."""
