@@ -26,8 +26,8 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 # -ffp-contract=off is part of the numerical contract (bit-exact inlier counts), not a tuning flag.
 # -fno-slp-vectorize: the SLP vectoriser turns pairs of scalar f32 ops into v_and/v_pk_* sequences that cost
-# more issue slots than they save on gfx950 (count kernel 0.435 -> 0.395 ms with it off); packing is done by hand
-# where it pays (k_count_fast).
+# more issue slots than they save on gfx950 (count kernel 0.435 -> 0.395 ms with it off)
+# (measured on the round-1 VALU kernel; kept: the SLP vectoriser has nothing to gain in these kernels).
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has a unified register file) instead of AGPRs plus one
 # v_accvgpr_read per value (k_count_bf16 consumes every result on the VALU).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",

@@ -6,7 +6,7 @@
 // ---------------------------------------------------------------------------------------------
 // Stage 3, matrix-core prefilter form (k_count_bf16).
 //
-// k_count_fast is bound by VALU issue (7.35 VALU instructions per evaluation, 84 % VALU busy); 4 of the 6.5
+// The sqrt/divide-free VALU kernel of round 1 (k_count_fast, removed) was bound by VALU issue (7.35 VALU instructions per evaluation, 84 % VALU busy); 4 of the 6.5
 // useful ones are the two dot products a = d.nh and b' = kappa d x nh.  Those are bilinear in (hx,hy,1) and the
 // pixel's (nh, -c.nh) / (B, -c.B): a rank-3 form.  The f32 MFMA shares the fp32 VALU datapath on gfx950
 // (tools/microbench/mfma_valu_overlap.hip: no overlap), but the bf16 matrix core is a separate pipe that does
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                                 const int prow = (j * 4 + wave) * 16 + ebase + (e & 3) + 8 * (e >> 2);
                                 const int p = pb + prow;
                                 const int fast = ((sgn >> (7 - e)) & 1u) ? 0 : 1;
-                                // second level: the sqrt/divide-free test of k_count_fast on d = fl(h - c) (the exact path's own
+                                // second level: the sqrt/divide-free test of round 1 (k_count_fast) on d = fl(h - c) (the exact path's own
                                 // d) with the f32 unit normal from LDS; its band (beta2, eps0) is ~10x narrower than the MFMA's
                                 const float4 rec = sP[prow];
                                 const float dx = hp.x - (rec.z + org.x), dy = hp.y - (rec.w + org.y);

@@ -324,7 +324,7 @@ def test_v3_subsample_with_injected_selection(oracle, synth, pkg, gpu):
 
 
 def test_v3_subsample_fused_into_compaction_at_480x640(oracle, synth, pkg, gpu):
-    """480x640 = 150 tiles: the subsampling of P:135-138 happens inside k_compact (no k_tile_subsample launch), every
+    """480x640 = 150 tiles: the subsampling of P:135-138 happens inside k_compact_hyp (no k_tile_subsample launch), every
     block redoing the draws of the tiles before it.  ~12 % foreground (37 k pixels > max_num = 30000), injected draws:
     tn, every count and the means must equal the oracle's; the second image (2 % foreground) is not subsampled."""
     from clean_pvnet_amd import ransac_voting as ext
