@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__re
     __shared__ int seg2[2][kTileSteps * 4 + 1];                    // double-buffered by the parity of the iteration: the
     __shared__ int red2[2][4];                                     // next tile's counts are written while stragglers still read
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    constexpr bool ahead = AHEAD;                                  // host: a.contig && !a.seg
+    // AHEAD (host: a.contig && !a.seg): the read-ahead instantiation
     raw_t cur[AHEAD ? kTileSteps : 1] = {};
     int g = blockIdx.x;
     if constexpr (AHEAD) if (g < total_tiles) {
