@@ -176,12 +176,13 @@ def main():
     # Splitting ONE call over streams loses instead (tools/two_stream.py), so the library does not do that by itself.
     two_stream = None
     if not use_dist and B > 0 and not args.no_two_stream:
-        side = [torch.cuda.Stream(), torch.cuda.Stream()]
+        from clean_pvnet_amd.pipeline import StreamRing
+        ring = StreamRing(2, dev)
         def alternating_step(i):
-            with torch.cuda.stream(side[i & 1]):
-                return vote(batches[i % len(batches)])
+            return ring.run(vote, batches[i % len(batches)])
         n2 = max(10, args.steps // 2)
         ts_el, _per, _o = run(alternating_step, 6, n2)
+        ring.join()
         two_stream = {"two_stream_images_per_s": round(global_batch * n2 / ts_el, 1), "two_stream_ms_per_step": round(1e3 * ts_el / n2, 4)}
 
     # N > 1 extras: weak scaling (global_batch images PER GPU) and the exchange overlapped with the next step's voting

@@ -1009,6 +1009,42 @@ def test_calls_on_two_streams_are_independent(synth, pkg, gpu):
         assert torch.equal(o, ref_c)
 
 
+def test_stream_ring_pipelines_a_sequence_of_batches(synth, pkg, gpu):
+    """clean_pvnet_amd.pipeline.StreamRing: consecutive batches on alternating streams, inputs produced on the current
+    stream right before each call, results consumed on the current stream after join() -- equal to the serial calls."""
+    from clean_pvnet_amd.pipeline import StreamRing
+    from clean_pvnet_amd.ransac_voting_gpu import estimate_voting_distribution_with_mean, ransac_voting_layer_v3
+    cfg = {**synth.CONFIGS["cfg2"], "B": 2}
+    data = [synth.make_batch(**cfg, seed=300 + i, device=gpu) for i in range(5)]
+    want = [ransac_voting_layer_v3(d["mask"], d["vertex"], 256, inlier_thresh=0.99, seed=40 + i) for i, d in enumerate(data)]
+    want_cov = [estimate_voting_distribution_with_mean(d["mask"], d["vertex"], w, 64, 512, seed=40 + i)[1]
+                for i, (d, w) in enumerate(zip(data, want))]
+    torch.cuda.synchronize()
+    ring = StreamRing(2)
+    got, got_cov = [], []
+    for i, d in enumerate(data):
+        mask = d["mask"].clone()                     # an input produced on the current stream just before the call
+        vertex = d["vertex"] * 1.0
+
+        def both(m, v, seed):
+            k = ransac_voting_layer_v3(m, v, 256, inlier_thresh=0.99, seed=seed)
+            return k, estimate_voting_distribution_with_mean(m, v, k, 64, 512, seed=seed)[1]
+        k, c = ring.run(both, mask, vertex, 40 + i)
+        got.append(k)
+        got_cov.append(c)
+        del mask, vertex                             # the allocator must not hand the memory out before the side stream is done
+    ring.join()
+    total = sum(g.sum() for g in got)                # consumed on the current stream
+    torch.cuda.synchronize()
+    assert torch.isfinite(total)
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    for g, w in zip(got_cov, want_cov):
+        assert torch.equal(g, w)
+    with pytest.raises(ValueError):
+        StreamRing(0)
+
+
 def test_foreground_sizes_around_tile_and_chunk_edges(oracle, pkg, gpu):
     """The count kernel cuts an image's tn compacted pixels into 512-pixel chunks and 16-pixel tiles that go round-robin
     to 4 waves, skipping empty tiles: tn just below / at / above every boundary (and one pixel over a chunk), all
