@@ -13,6 +13,11 @@ so this is a few lines of stream bookkeeping on the caller's side -- ``StreamRin
         results.append(kpt)                             # not yet ordered against the current stream
     ring.join()                                         # now the current stream sees every result
 
+The bookkeeping costs ~10-15 us of host time per run() (an event, two stream switches), so it pays for calls that keep
+the GPU busy longer than that -- B >= 32 at 480x640; a shard of 8 images (64 us per call) is host-bound either way
+(``tools/ring_streams.py``: 224 -> 273 k images/s at B = 64 with two streams, three or four are not better; 92 -> 123 k at
+B = 8 against 128 k for plain calls on one stream).
+
 The reference has no counterpart (its evaluation loop is one image at a time on the default stream,
 lib/evaluators/linemod/pvnet.py:166-186).
 """
