@@ -38,7 +38,7 @@
   `k_select_refit` {{cold_refit}}, `k_finalize_v3` {{cold_fin}}; replaying one warm batch without pre-warm
   (`profiles/r02_gaps_cfg3_B64.json`): {{warm}} µs (round 1, same protocol: 28.8 + 24.5 + 11.7 + 218.9 + 15.2 + 4.6 =
   304 µs).  The same steps alternating over two streams, as a caller decoding a sequence of batches can issue them
-  (`extra.two_stream_images_per_s`, never `value`): **{{ts}} k images/s**.  Extras
+  (`clean_pvnet_amd.pipeline.StreamRing`; `extra.two_stream_images_per_s`, never `value`): **{{ts}} k images/s**.  Extras
   (`r02_bench_extras.json`): B = 1 latency {{b1}} µs/call (round 1: 38); v3 + estimate (4096 hypotheses) {{est}} k images/s;
   fused `decode_keypoint` {{df}} k vs {{du}} k images/s for `torch.argmax` + v3; un_pnp one pass {{one}} k vs {{two}} k; the
   reference's default non-`un_pnp` call {{dp}} k images/s (round 1: 769 k).  Host-buffer note: the boundary takes device
