@@ -29,6 +29,7 @@ struct MaskArgs {
     uint64_t seed;
     int b0;                  // first_image: RNG key offset of image 0
     int *tn_user;            // the caller's tn[B] (or nullptr): written beside the workspace copy, no D2D copy later
+    int *status;             // the caller's status[B] (or nullptr): PVV_STATUS_* bits, written with tn
     int fuse_sub;            // 1: k_compact_hyp applies the subsampling itself (no k_tile_subsample launch), see there
     int want_draws;          // 1: subsampling is possible at all (max_num below the largest foreground_num the mask can
                              //    have): k_tile_scan stores every foreground pixel's U(0,1) draw beside its list entry
@@ -421,10 +422,14 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
                     nsurv += red[0] + red[1] + red[2] + red[3];
                 }
             }
-            nsurv = nsurv < kSurvCap ? nsurv : kSurvCap;
             __threadfence_block();
             __syncthreads();
-            if (nsurv < tn) tn = nsurv;                           // what the compaction blocks will report (cap applies there)
+            // More survivors than the list holds: impossible for the device RNG (its binomial is >= 40 sigma below kSurvCap
+            // for the <= 160-tile images that fuse) but an injected selection tensor may keep any number.  Then
+            // at least kSurvCap / (160 * 2048) = 1/40 of the listed pixels survive and rejection sampling (below) finds one
+            // in a few tries -- uniform over ALL survivors, nothing truncated.
+            if (nsurv > kSurvCap) nsurv = -1;
+            else if (nsurv < tn) tn = nsurv;                      // what the compaction blocks will report (cap applies there)
         }
 
         const int gid = j * kBlock + threadIdx.x;                 // hypothesis (vi, hi) of image b
@@ -463,16 +468,18 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
             } else {
                 p0 = p1 = -1;
                 for (int tr = 0; tr < kHypRejectTries && (p0 < 0 || p1 < 0); ++tr) {
-                    // try tr of draw c: key (stream + 16, image, c + tr * 2^24)  -- hn * K * 2 < 2^24 (validate())
+                    // try tr of draw c: key (stream + 16 + 4 tr, image, c).  The try index goes into the STREAM word, where it
+                    // cannot wrap (`c + (tr << 24)` wrapped at tr = 256, so tries 256.. replayed tries 0..255 and a
+                    // draw that had failed 256 times failed 4096 times); the streams in use are 1 and 3, so 17 + 4 tr and
+                    // 19 + 4 tr never meet, and 0 (the subsample draws) is never touched.
                     size_t e;
+                    const uint32_t stry = stream + 16u + 4u * (uint32_t)tr;
                     if (p0 < 0) {
-                        const int p = select_pixel(s_prefix, a.T, img_lists,
-                                                   (int)(rng_u32(a.seed, stream + 16u, img, c + ((uint32_t)tr << 24)) % (uint32_t)total), &e);
+                        const int p = select_pixel(s_prefix, a.T, img_lists, (int)(rng_u32(a.seed, stry, img, c) % (uint32_t)total), &e);
                         if (img_draws[e] < prob) p0 = p;
                     }
                     if (p1 < 0) {
-                        const int p = select_pixel(s_prefix, a.T, img_lists,
-                                                   (int)(rng_u32(a.seed, stream + 16u, img, c + 1u + ((uint32_t)tr << 24)) % (uint32_t)total), &e);
+                        const int p = select_pixel(s_prefix, a.T, img_lists, (int)(rng_u32(a.seed, stry, img, c + 1u) % (uint32_t)total), &e);
                         if (img_draws[e] < prob) p1 = p;
                     }
                 }
@@ -508,6 +515,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
         if (t == 0 && threadIdx.x == 0) {
             tn_out[b] = 0;
             if (a.tn_user) a.tn_user[b] = 0;
+            if (a.status) a.status[b] = PVV_STATUS_SKIPPED;
         }
         return;
     }
@@ -534,11 +542,15 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
             const int all = before + tile_n;
             tn_out[b] = all < a.cap ? all : a.cap;
             if (a.tn_user) a.tn_user[b] = tn_out[b];
+            if (a.status) a.status[b] = PVV_STATUS_SUBSAMPLED | (all > a.cap ? PVV_STATUS_TRUNCATED : 0);
         }
     } else {
         if (t == 0 && threadIdx.x == 0) {
             tn_out[b] = tot.total < a.cap ? tot.total : a.cap;
             if (a.tn_user) a.tn_user[b] = tn_out[b];
+            // not fused: k_tile_subsample has already rewritten the lists of an image with foreground_num > max_num
+            if (a.status) a.status[b] = (tot.fg > (long long)a.max_num ? PVV_STATUS_SUBSAMPLED : 0) |
+                                        (tot.total > a.cap ? PVV_STATUS_TRUNCATED : 0);
         }
 #pragma unroll
         for (int s = 0; s < kTileSteps; ++s) {

@@ -95,12 +95,43 @@ __device__ __forceinline__ int stage_hypothesis(bf16x8 *sB, int *sCnt, int i, fl
 #define PVV_CENSUS_OUT(n) do { } while (0)
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// Staged counting (ransac_voting_layer_v3 only): the layer needs the ARG-MAX of the counts and the winner's count
+// (P:160-167), not the counts.  A launch of k_count_bf16<true> counts only the 512-pixel chunks whose index has a residue
+// (mod M) in `mask`, and only the hypotheses that k_prune left alive: after stage s a hypothesis whose partial count plus
+// ALL pixels not yet counted stays below the exactly known full count of a leader can neither win nor tie and is dropped
+// (count_prune.hpp).  Survivors end with their exact full count, dropped ones with a partial count below the maximum:
+// winner, first-index tie rule and winner count are those of the full pass, bit for bit.
+// ---------------------------------------------------------------------------------------------
+struct StageArgs {
+    uint32_t mask;        // residues (mod M) of the chunks this launch counts
+    int M;                // period of the chunk schedule (<= 31)
+    const float2 *hyp;    // [B,K,hn] the hypotheses this launch evaluates, dense from the front of every row
+    const int *idx;       // [B,K,hn] their indices in the hypothesis array, or nullptr = identity (first stage)
+    const int *ns;        // [B,K] how many per (image, keypoint), or nullptr = hn (first stage)
+};
+
+// chunks with a residue in `mask` among the first n chunks, and the j-th of them (residues present in a last, partial
+// period are a prefix of the sorted residues, so the j-th chunk does not depend on n)
+__device__ __forceinline__ int stage_chunks(uint32_t mask, int M, int n)
+{
+    return (n / M) * __popc(mask) + __popc(mask & ((1u << (n % M)) - 1u));
+}
+__device__ __forceinline__ int stage_chunk_at(uint32_t mask, int M, int j)
+{
+    const int m = __popc(mask), per = j / m;
+    uint32_t t = mask;
+    for (int k = j - per * m; k > 0; --k) t &= t - 1u;
+    return per * M + __builtin_ctz(t);
+}
+
 // 5 blocks (= 5 waves per SIMD) per CU: <= 96 VGPRs and 30 KB of LDS per block; measured -4.4 % against 4
+template <bool STAGED>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_count_bf16(
     const float2 *__restrict__ coords /*[B,cap]*/, const float2 *__restrict__ dirs /*[B,K,cap]*/,
     const float2 *__restrict__ hyps /*[B,K,hn]*/, int *__restrict__ counts /*[B,K,hn]*/,
     const int *__restrict__ tn_arr, int B, int K, int hn, int cap, float thresh, Bf16Consts fc, int target_items,
-    long long *__restrict__ dbg /*tuning builds: phase timestamps; nullptr otherwise*/)
+    long long *__restrict__ dbg /*tuning builds: phase timestamps; nullptr otherwise*/, StageArgs sa)
 {
     PVV_STAMP(0);
     PVV_CENSUS_IN();
@@ -125,6 +156,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         for (int b0 = 0; b0 < B; b0 += 64) {
             const int b = b0 + lane;
             int inc = b < B ? (tn_arr[b] + PC - 1) / PC : 0;
+            if constexpr (STAGED) inc = stage_chunks(sa.mask, sa.M, inc);   // this stage's chunks of the image
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const int m = __shfl_up(inc, o, 64);
@@ -170,12 +202,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         const int gchunk = item / per_chunk;                    // chunk index over the whole batch
         const int rem = item - gchunk * per_chunk;
         int local;
-        const int b = locate_item(chunk_end, B, gchunk, &local);   // image, and the chunk's index within it
-        const int chunk = local;
+        const int b = locate_item(chunk_end, B, gchunk, &local);   // image, and the chunk's index within it (this stage's)
+        const int chunk = STAGED ? stage_chunk_at(sa.mask, sa.M, local) : local;
         const int vi = rem / nruns;
         const int run = rem - vi * nruns;
         const int bk = b * K + vi;
-        const float2 *hyp_k = hyps + (size_t)bk * hn;
+        const float2 *hyp_k = (STAGED ? sa.hyp : hyps) + (size_t)bk * hn;
         const float2 *crd = coords + (size_t)b * cap;
         const float2 *dir_k = dirs + (size_t)bk * cap;
         const int pb = chunk * PC;                              // first pixel of the block's chunk (< tn)
@@ -188,6 +220,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         //      per thread (rows beyond tn are read -- the arrays reserve cap rows -- and masked below) and the
         //      hypotheses of the first group.  One memory round trip instead of three.
         const int tn_v = tn_arr[b];
+        int hn_v = hn;                                          // hypotheses alive for this (image, keypoint)
+        if constexpr (STAGED) if (sa.ns) hn_v = sa.ns[bk];
         const float2 org = crd[pb];                             // integer origin: the chunk's first pixel
         float2 pc[2], pd[2];
 #pragma unroll
@@ -205,6 +239,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             hp0[q] = (i < nht0 * 32 && h < hn) ? hyp_k[h] : make_float2(0.f, 0.f);
         }
         const int tn = __builtin_amdgcn_readfirstlane(tn_v);
+        const int hn_k = STAGED ? __builtin_amdgcn_readfirstlane(hn_v) : hn;
+        const int nt_k = STAGED ? (hn_k + 31) >> 5 : nt;          // 32-hypothesis tiles of this (image, keypoint)
+        if constexpr (STAGED) {
+            if (g0 * htpi >= nt_k) continue;                     // block-uniform: this run of groups holds no survivor
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                        // rows beyond the survivors hold stale entries
+                const int i = threadIdx.x + q * kBlock;
+                if ((g0 * htpi + (i >> 5)) * 32 + (i & 31) >= hn_k) hp0[q] = make_float2(0.f, 0.f);
+            }
+        }
 
         // ---- per pixel (two per thread): the f32 unit normal and the translated coordinates (16 bytes of LDS; the
         //      kappa-scaled perpendicular and the constants -(c-o).nh, -(c-o).B are formed where they are used).  A pixel
@@ -234,10 +278,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         if (lane == 0) sRed[wave] = c1;
         // ---- B operands of the first group (see stage_group below for the layout)
         int far = 0;
+        const int nht0_k = STAGED ? min(nt_k, (g0 + 1) * htpi) - g0 * htpi : nht0;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int i = threadIdx.x + q * kBlock;
-            if (i < nht0 * 32) far |= stage_hypothesis(sB, sCnt, i, hp0[q], org);
+            if (i < nht0_k * 32) far |= stage_hypothesis(sB, sCnt, i, hp0[q], org);
         }
         far = __syncthreads_or(far);
         PVV_STAMP(4);
@@ -297,13 +342,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 
         for (int g = g0; g < g1; ++g) {
             const int ht0 = g * htpi;
-            const int nht = min(nt, ht0 + htpi) - ht0;
+            const int nht = min(nt_k, ht0 + htpi) - ht0;
+            if (STAGED && nht <= 0) break;                       // block-uniform
             if (g > g0) {
                 // ---- B operands of the next group (the first group's were staged with the pixels)
                 far = 0;
                 for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
                     const int h = (ht0 + (i >> 5)) * 32 + (i & 31);
-                    far |= stage_hypothesis(sB, sCnt, i, h < hn ? hyp_k[h] : make_float2(0.f, 0.f), org);
+                    far |= stage_hypothesis(sB, sCnt, i, h < hn_k ? hyp_k[h] : make_float2(0.f, 0.f), org);
                 }
                 far = __syncthreads_or(far);
             }
@@ -313,7 +359,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 // some hypothesis of the group is non-finite / astronomically far: exact loop (K:100-125)
                 for (int ht = 0; ht < nht; ++ht) {
                     const int h = (ht0 + ht) * 32 + col;
-                    if (h >= hn) continue;
+                    if (h >= hn_k) continue;
                     const float2 hp = hyp_k[h];
                     int inl = 0;
                     for (int p = pb + wave * 2 + kslice; p < min(tn, pb + PC); p += 8) {
@@ -369,7 +415,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                     // more issue slots in every iteration than the stall does in a sixth of them, measured +1.6 %)
                     if (__builtin_expect(flagged != 0u, 0) && __any((mb[0] | mb[1]) != 0u)) {
                         const int h = (ht0 + ht) * 32 + col;
-                        const float2 hp = h < hn ? hyp_k[h] : make_float2(0.f, 0.f);
+                        const float2 hp = h < hn_k ? hyp_k[h] : make_float2(0.f, 0.f);
                         do {
                             // re-decide the marked evaluations of tile j exactly (K:100-125)
                             const int j = __builtin_ctz(flagged);
@@ -416,7 +462,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
                 const int h = ht0 * 32 + i;
                 const int c = sCnt[i];
-                if (h < hn && c != 0) atomicAdd(&counts[(size_t)bk * hn + h], c);
+                if (h < hn_k && c != 0) {
+                    int dst = h;                                     // survivor row -> index in the hypothesis array
+                    if constexpr (STAGED) if (sa.idx) dst = sa.idx[(size_t)bk * hn + h];
+                    atomicAdd(&counts[(size_t)bk * hn + dst], c);
+                }
             }
             PVV_STAMP(8);
         }

@@ -181,6 +181,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_uncertainty_pnp(
     for (int k = 0; k < 6; ++k) g[k] = s_sum[wave][21 + k];
     cost = s_sum[wave][27];
     const double initial_cost = cost;
+    // Ceres' Jacobi scaling: column i is scaled by 1 / (1 + |J_i|) with the norms of the INITIAL point (trust_region_minimizer);
+    // the LM diagonal is the squared norm of the SCALED column clamped to [min_lm_diagonal, max_lm_diagonal] = [1e-6, 1e32]
+    // (levenberg_marquardt_strategy).  In unscaled coordinates: damping_i = clamp(JtJ_ii s_i^2) / (s_i^2 radius)  (ADVICE r2).
+    double jscale2[6];
+    {
+        int idx = 0;
+        for (int u = 0; u < 6; ++u) {
+            const double sc = 1.0 / (1.0 + sqrt(JtJ[idx]));
+            jscale2[u] = sc * sc;
+            idx += 6 - u;
+        }
+    }
     const int limit = max_iter > 0 ? max_iter : 50;
     int it = 0, term = 0;
     for (; it < limit; ++it) {
@@ -191,9 +203,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_uncertainty_pnp(
         {
             int idx = 0;
             for (int u = 0; u < 6; ++u) {
-                double di = sqrt(JtJ[idx]);
-                di = fmin(fmax(di, 1e-6), 1e32);
-                d[u] = di * di / radius;
+                const double di = fmin(fmax(JtJ[idx] * jscale2[u], 1e-6), 1e32);
+                d[u] = di / (jscale2[u] * radius);
                 ng[u] = -g[u];
                 idx += 6 - u;
             }

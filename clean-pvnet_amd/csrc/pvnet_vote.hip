@@ -60,6 +60,7 @@ int check_launch(const char *what)
 #include "compaction.hpp"
 #include "count_exact.hpp"
 #include "count_bf16.hpp"
+#include "count_prune.hpp"
 #include "refit.hpp"
 #include "covariance.hpp"
 #include "legacy_kernels.hpp"
@@ -72,7 +73,11 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Layout {
     int T;
     size_t tiles, tile_list, tile_draw, tn, surv, coords, dirs, hyps, counts, sums, total;
+    size_t alive_idx[2], alive_hyp[2], alive_n[2];   // staged counting (count_prune.hpp): survivors, ping-pong; 0 = not reserved
 };
+
+bool use_bf16_count(const pvv_problem *p);
+bool may_stage(const pvv_problem *p);
 
 Layout make_layout(const pvv_problem *p)
 {
@@ -91,6 +96,13 @@ Layout make_layout(const pvv_problem *p)
     L.hyps = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
     L.counts = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
     L.sums = take(sizeof(double) * (size_t)p->B * p->K * kRefitSplitMax * 5);
+    for (int i = 0; i < 2; ++i) L.alive_idx[i] = L.alive_hyp[i] = L.alive_n[i] = 0;
+    if (may_stage(p))
+        for (int i = 0; i < 2; ++i) {
+            L.alive_idx[i] = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
+            L.alive_hyp[i] = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
+            L.alive_n[i] = take(sizeof(int) * (size_t)p->B * p->K);
+        }
     L.total = off;
     return L;
 }
@@ -103,7 +115,7 @@ int validate(const pvv_problem *p)
     if (p->B > kMaxBatchLds) return fail(PVV_E_ARG, "B > 1024: split the batch");
     if (((long long)p->H * p->W + kTile - 1) / kTile > kMaxTiles) return fail(PVV_E_ARG, "H*W too large (more than 16000 tiles of 2048 pixels)");
     if ((long long)p->K * p->hn >= (1ll << 23)) return fail(PVV_E_ARG, "K*hn must be < 2^23");
-    if (p->count_kernel != PVV_COUNT_AUTO && p->count_kernel != PVV_COUNT_EXACT) return fail(PVV_E_ARG, "unknown count_kernel");
+    if (p->count_kernel < PVV_COUNT_AUTO || p->count_kernel > PVV_COUNT_STAGED) return fail(PVV_E_ARG, "unknown count_kernel");
     if (p->mask_elem_size != 1 && p->mask_elem_size != 2 && p->mask_elem_size != 4 &&
         p->mask_elem_size != 8)
         return fail(PVV_E_ARG, "mask_elem_size must be 1, 2, 4 or 8");
@@ -150,8 +162,22 @@ int launch_count(const CountArgs &a, hipStream_t st)
 // (pvv_problem.count_kernel = PVV_COUNT_EXACT: the tests' cross-check) the exact kernel counts.
 bool use_bf16_count(const pvv_problem *p)
 {
-    return p->count_kernel == PVV_COUNT_AUTO && p->inlier_thresh >= 0.5f && p->inlier_thresh <= 0.99995f &&
+    return p->count_kernel != PVV_COUNT_EXACT && p->inlier_thresh >= 0.5f && p->inlier_thresh <= 0.99995f &&
            p->H <= 16384 && p->W <= 16384;
+}
+
+// Staged counting with exact elimination (count_bf16.hpp / count_prune.hpp) is something only ransac_voting_layer_v3
+// can use (it keeps the arg-max; the estimate weighs every hypothesis).  may_stage: the workspace reserves the survivor
+// lists (a property of the problem alone, so that pvv_workspace_bytes needs no extra argument); stage_v3: this v3 call
+// takes the staged path.  PVV_COUNT_STAGED forces it wherever the matrix-core kernel is valid, PVV_COUNT_FULL forbids
+// it, AUTO stages when the batch is large enough for the two extra launches (k_prune + the second count launch,
+// ~8 us) to pay: measured on MI355X at 480x640 / 512 hypotheses -- see DESIGN.md 4.6.
+constexpr long long kStageMinPixels = 12ll * 480 * 640;
+bool may_stage(const pvv_problem *p)
+{
+    if (!use_bf16_count(p) || p->count_kernel == PVV_COUNT_FULL) return false;
+    if (p->count_kernel == PVV_COUNT_STAGED) return true;
+    return p->hn >= 128 && (long long)p->B * p->H * p->W >= kStageMinPixels;
 }
 
 Bf16Consts bf16_consts(float thresh)
@@ -200,7 +226,34 @@ long long *tuning_ptr(const char *name)
 #endif
 }
 
-int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st)
+// optional stage-boundary events (pvv_problem.ev_marks, a measurement aid): mark i is recorded on the call's stream
+int mark(const pvv_problem *p, int i, hipStream_t st)
+{
+    if (!p->ev_marks || !p->ev_marks[i]) return PVV_OK;
+    if (hipEventRecord((hipEvent_t)p->ev_marks[i], st) != hipSuccess) return fail(PVV_E_ARG, "ev_marks holds an invalid hipEvent_t");
+    return PVV_OK;
+}
+
+// The chunk schedule of the staged count: stage s counts the 512-pixel chunks c with (c mod M) in mask[s].  Two stages:
+// a quarter of the chunks, spread over the object (rows of the compacted list = raster order), then -- for the
+// hypotheses k_prune left alive -- the rest.
+struct StageSchedule { int n, M; uint32_t mask[4]; };
+StageSchedule stage_schedule()
+{
+    StageSchedule sc;
+    sc.n = tuning_int("PVV_STAGES", 2);
+    sc.M = tuning_int("PVV_STAGE_M", 8);
+    const uint32_t all = (1u << sc.M) - 1u;
+    sc.mask[0] = (uint32_t)tuning_int("PVV_STAGE_MASK0", 0x22) & all;          // residues 1 and 5 of 8
+    sc.mask[1] = (uint32_t)tuning_int("PVV_STAGE_MASK1", sc.n > 2 ? 0x88 : 0) & all;
+    sc.mask[2] = (uint32_t)tuning_int("PVV_STAGE_MASK2", 0) & all;
+    uint32_t used = 0;
+    for (int i = 0; i < sc.n - 1; ++i) { sc.mask[i] &= ~used; used |= sc.mask[i]; }
+    sc.mask[sc.n - 1] = all & ~used;                                            // the last stage: everything left
+    return sc;
+}
+
+int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, bool staged)
 {
     // persistent blocks per CU (5 are resident): every block builds the item table once, so few blocks are better when
     // items are short (hn <= 512: one hypothesis group per item), more when they are long and uneven; several
@@ -221,11 +274,50 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     // The host does not know tn: up to B = 8 it launches the one generation, beyond that 15 per CU (48 for >= 2048
     // hypotheses: long, uneven items) and the KERNEL falls back to one generation when it finds few items (count_bf16.hpp).
     const int per_cu = per_cu_t > 0 ? per_cu_t : (p->B <= 8 ? 5 : (p->hn < 2048 ? 15 : 48));
-    hipLaunchKernelGGL(k_count_bf16, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, (const float2 *)(ws + L.coords),
-                       (const float2 *)(ws + L.dirs), (const float2 *)(ws + L.hyps), (int *)(ws + L.counts),
-                       (const int *)(ws + L.tn), p->B, p->K, p->hn, p->cap, p->inlier_thresh,
-                       bf16_consts(p->inlier_thresh), tuning_int("PVV_TARGET_ITEMS", items_per_cu * num_cus()), tuning_ptr("PVV_DBG_PTR"));
-    return check_launch("k_count_bf16");
+    const float2 *coords = (const float2 *)(ws + L.coords), *dirs = (const float2 *)(ws + L.dirs);
+    const float2 *hyps = (const float2 *)(ws + L.hyps);
+    int *counts = (int *)(ws + L.counts);
+    const int *tn = (const int *)(ws + L.tn);
+    const Bf16Consts fc = bf16_consts(p->inlier_thresh);
+    const int target = tuning_int("PVV_TARGET_ITEMS", items_per_cu * num_cus());
+    long long *dbg = tuning_ptr("PVV_DBG_PTR");
+    if (!staged) {
+        hipLaunchKernelGGL(k_count_bf16<false>, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
+                           p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target, dbg, StageArgs{0u, 1, nullptr, nullptr, nullptr});
+        return check_launch("k_count_bf16");
+    }
+    // ransac_voting_layer_v3, staged: count a spread quarter of the chunks for every hypothesis, drop the hypotheses that
+    // can no longer reach a leader's exactly known full count, count the rest for the survivors (count_prune.hpp)
+    const StageSchedule sc = stage_schedule();
+    uint32_t done = 0;
+    for (int s = 0; s < sc.n; ++s) {
+        StageArgs sa;
+        sa.mask = sc.mask[s];
+        sa.M = sc.M;
+        const int in = (s - 1) & 1, out = s & 1;
+        sa.hyp = s == 0 ? hyps : (const float2 *)(ws + L.alive_hyp[in]);
+        sa.idx = s == 0 ? nullptr : (const int *)(ws + L.alive_idx[in]);
+        sa.ns = s == 0 ? nullptr : (const int *)(ws + L.alive_n[in]);
+        if (sa.mask) {
+            hipLaunchKernelGGL(k_count_bf16<true>, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
+                               p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target, dbg, sa);
+            if (int e = check_launch("k_count_bf16<staged>")) return e;
+        }
+        done |= sa.mask;
+        if (s == 0) if (int e = mark(p, PVV_MARK_STAGE0, st)) return e;
+        if (s == sc.n - 1) break;
+        PruneArgs pa;
+        pa.tn_arr = tn; pa.coords = coords; pa.dirs = dirs; pa.hyps = hyps; pa.counts = counts;
+        pa.idx_in = sa.idx; pa.ns_in = sa.ns;
+        pa.hyp_out = (float2 *)(ws + L.alive_hyp[out]); pa.idx_out = (int *)(ws + L.alive_idx[out]);
+        pa.ns_out = (int *)(ws + L.alive_n[out]);
+        pa.K = p->K; pa.hn = p->hn; pa.cap = p->cap; pa.thresh = p->inlier_thresh;
+        pa.done_mask = done; pa.M = sc.M;
+        hipLaunchKernelGGL(k_prune, dim3(p->K, p->B), dim3(kBlock), 0, st, pa);
+        if (int e = check_launch("k_prune")) return e;
+        if (s == 0) if (int e = mark(p, PVV_MARK_PRUNE0, st)) return e;
+    }
+    return PVV_OK;
 }
 
 CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
@@ -245,11 +337,13 @@ CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
     return a;
 }
 
-int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st)
+// v3: the call is ransac_voting_layer_v3 proper (not the estimate, not the fused un_pnp pass), which may count in stages
+int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, bool v3)
 {
     if (p->ev_count_begin && hipEventRecord((hipEvent_t)p->ev_count_begin, st) != hipSuccess)
         return fail(PVV_E_ARG, "ev_count_begin is not a valid hipEvent_t");
-    const int e = use_bf16_count(p) ? launch_count_bf16(p, L, ws, st) : launch_count(planar_count_args(p, L, ws), st);
+    const bool staged = v3 && may_stage(p) && L.alive_n[0] != 0;
+    const int e = use_bf16_count(p) ? launch_count_bf16(p, L, ws, st, staged) : launch_count(planar_count_args(p, L, ws), st);
     if (e) return e;
     if (p->ev_count_end && hipEventRecord((hipEvent_t)p->ev_count_end, st) != hipSuccess)
         return fail(PVV_E_ARG, "ev_count_end is not a valid hipEvent_t");
@@ -314,6 +408,7 @@ Front make_front(const pvv_problem *p, int mode, const void *d_mask, const float
     m.seed = p->seed;
     m.b0 = p->first_image;
     m.tn_user = d_tn;
+    m.status = p->d_status;
     // Subsampling inside k_compact_hyp (no k_tile_subsample launch) only for images of <= kFuseSubTiles tiles, only when
     // subsampling is unlikely -- max_num at least 1/16 of the image (30000 of 307200) -- and only with the device RNG:
     // injected index pairs address rows of the SUBSAMPLED list, which the hypothesis blocks can read off the tile lists
@@ -357,22 +452,27 @@ int run_scan(const pvv_problem *p, const Front &f, char *ws, const Layout &L, hi
 int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d_vertex,
               const int32_t *d_idxs, const float *d_selection, char *ws, const Layout &L,
               hipStream_t st, int32_t *d_tn, const float *d_seg = nullptr, int64_t *d_mask_out = nullptr,
-              const int32_t *d_idxs2 = nullptr, int hn_first = -1, uint32_t stream_first = 1u, uint32_t stream_rest = 3u)
+              const int32_t *d_idxs2 = nullptr, int hn_first = -1, uint32_t stream_first = 1u, uint32_t stream_rest = 3u,
+              bool v3 = false)
 {
     const Front f = make_front(p, mode, d_mask, d_vertex, d_idxs, d_selection, ws, L, d_tn, d_seg, d_mask_out, d_idxs2,
                                hn_first, stream_first, stream_rest);
+    if (int e = mark(p, PVV_MARK_BEGIN, st)) return e;
     if (int e = run_scan(p, f, ws, L, st)) return e;
     if (!f.m.fuse_sub && f.can_subsample) {
         hipLaunchKernelGGL(k_tile_subsample, dim3(L.T, p->B), dim3(kBlock), 0, st, f.m, (uint32_t *)(ws + L.tiles),
                            (unsigned short *)(ws + L.tile_list), (const float *)(ws + L.tile_draw));
         if (int e = check_launch("k_tile_subsample")) return e;
     }
+    if (int e = mark(p, PVV_MARK_SCAN, st)) return e;
     hipLaunchKernelGGL(k_compact_hyp, dim3(L.T + f.h.blocks, p->B), dim3(kBlock), sizeof(int) * (size_t)L.T, st, f.m, f.v,
                        f.h, (const uint32_t *)(ws + L.tiles), (const unsigned short *)(ws + L.tile_list),
                        (const float *)(ws + L.tile_draw), (int *)(ws + L.tn), (float2 *)(ws + L.coords),
                        (float2 *)(ws + L.dirs));
     if (int e = check_launch("k_compact_hyp")) return e;
-    return launch_count_any(p, L, ws, st);
+    if (int e = mark(p, PVV_MARK_COMPACT, st)) return e;
+    if (int e = launch_count_any(p, L, ws, st, v3)) return e;
+    return mark(p, PVV_MARK_COUNT, st);
 }
 
 int check_ptrs(const pvv_problem *p, const void *mask, const void *vertex, void *ws, size_t ws_bytes,
@@ -424,10 +524,11 @@ static int finish_v3(const pvv_problem *p, const Layout &L, char *ws, float *d_o
                        (const int *)(ws + L.counts), (double *)(ws + L.sums), d_win_counts, p->K, p->hn, hstride,
                        p->cap, p->inlier_thresh, nsplit);
     if (int e = check_launch("k_select_refit")) return e;
+    if (int e = mark(p, PVV_MARK_SELECT, st)) return e;
     hipLaunchKernelGGL(k_finalize_v3, dim3(p->B), dim3(64), 0, st, (const int *)(ws + L.tn),
                        (const double *)(ws + L.sums), (float2 *)d_out, p->K, p->singular_policy, nsplit);
     if (int e = check_launch("k_finalize_v3")) return e;
-    return PVV_OK;
+    return mark(p, PVV_MARK_END, st);
 }
 
 PVV_EXPORT int pvv_ransac_voting_v3(const pvv_problem *p, const void *d_mask, const float *d_vertex,
@@ -440,7 +541,8 @@ PVV_EXPORT int pvv_ransac_voting_v3(const pvv_problem *p, const void *d_mask, co
     if (!d_out) return fail(PVV_E_ARG, "d_out is NULL");
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)d_workspace;
-    if (int e = run_front(p, 0, d_mask, d_vertex, d_idxs, d_selection, ws, L, st, d_tn)) return e;
+    if (int e = run_front(p, 0, d_mask, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, nullptr, nullptr, nullptr, -1, 1u, 3u, true))
+        return e;
     return finish_v3(p, L, ws, d_out, d_win_counts, st);
 }
 
@@ -456,7 +558,8 @@ PVV_EXPORT int pvv_decode_keypoint_v3(const pvv_problem *p, const float *d_seg, 
     if (p->seg_classes < 1 || p->seg_classes > 256) return fail(PVV_E_ARG, "seg_classes must be in [1, 256]");
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)d_workspace;
-    if (int e = run_front(p, 0, nullptr, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, d_seg, d_mask_out)) return e;
+    if (int e = run_front(p, 0, nullptr, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, d_seg, d_mask_out, nullptr, -1, 1u, 3u, true))
+        return e;
     return finish_v3(p, L, ws, d_out, d_win_counts, st);
 }
 
@@ -478,7 +581,7 @@ PVV_EXPORT int pvv_estimate_voting_distribution(const pvv_problem *p, const void
                        (const int *)(ws + L.counts), (const float2 *)d_mean, d_cov, (float2 *)d_hyp,
                        d_counts, d_weights, p->K, p->hn, p->hn, 0);
     if (int e = check_launch("k_covariance")) return e;
-    return PVV_OK;
+    return mark(p, PVV_MARK_END, st);
 }
 
 // resnet18.py:65-72 with cfg.test.un_pnp as ONE pass (see the header): the row of every (image, keypoint) holds the hn
@@ -530,6 +633,12 @@ PVV_EXPORT int pvv_decode_keypoint_un_pnp(const pvv_problem *p, int32_t hn_est, 
 PVV_EXPORT int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace, size_t workspace_bytes,
                                       int zero_counts, void *stream)
 {
+    // The count pass of a v3 call: staged when the call itself was -- but only with cleared counters: the elimination
+    // compares PARTIAL counts, stale totals would change which hypotheses survive.  zero_counts = 0 therefore re-runs the
+    // FULL kernel (what it always did), and is refused when the caller explicitly asked for PVV_COUNT_STAGED.
+    if (p && p->count_kernel == PVV_COUNT_STAGED && !zero_counts)
+        return fail(PVV_E_ARG, "a staged count pass needs zero_counts = 1");
+    const bool v3 = zero_counts != 0;
     if (int e = validate(p)) return e;
     if (!d_workspace) return fail(PVV_E_ARG, "workspace is NULL");
     Layout L = make_layout(p);
@@ -540,7 +649,38 @@ PVV_EXPORT int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace, s
         hipError_t e = hipMemsetAsync(ws + L.counts, 0, sizeof(int) * (size_t)p->B * p->K * p->hn, st);
         if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     }
-    return launch_count_any(p, L, ws, st);
+    return launch_count_any(p, L, ws, st, v3);
+}
+
+// ---- streaming-read probe (bench aid; SURVEY 8(d): what a read-once stream reaches on this box) ------------------
+namespace {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kBlock) void k_stream_read(const u32x4 *__restrict__ src, size_t n16, uint32_t *__restrict__ sink)
+{
+    // persistent grid, every lane four independent 16-byte loads per trip (64 B in flight per lane), non-temporal: the
+    // data is read once
+    uint32_t acc = 0;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        acc += (a.x ^ a.y ^ a.z ^ a.w) + (b.x ^ b.y ^ b.z ^ b.w) + (c.x ^ c.y ^ c.z ^ c.w) + (d.x ^ d.y ^ d.z ^ d.w);
+    }
+    for (; i < n16; i += stride) {
+        const u32x4 a = __builtin_nontemporal_load(src + i);
+        acc += a.x ^ a.y ^ a.z ^ a.w;
+    }
+    acc = wave_sum(acc);
+    if (lane_id() == 0 && acc == 0x9e3779b9u) atomicAdd(sink, acc);   // practically never: the sum only has to be observable
+}
+}  // namespace
+
+PVV_EXPORT int pvv_stream_read_probe(const void *d_buf, size_t bytes, uint32_t *d_sink, void *stream)
+{
+    if (!d_buf || !d_sink || bytes < 16 || (bytes & 15) || ((uintptr_t)d_buf & 15)) return fail(PVV_E_ARG, "probe: 16-byte aligned buffer and size");
+    hipLaunchKernelGGL(k_stream_read, dim3(num_cus() * 8), dim3(kBlock), 0, (hipStream_t)stream, (const u32x4 *)d_buf, bytes / 16, d_sink);
+    return check_launch("k_stream_read");
 }
 
 // ---- legacy module surface ---------------------------------------------------------------

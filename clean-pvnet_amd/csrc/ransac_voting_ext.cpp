@@ -240,14 +240,25 @@ at::Tensor make_workspace(const pvv_problem &p, const at::Tensor &like)
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> ransac_voting_v3(
     at::Tensor mask, at::Tensor vertex, int64_t round_hyp_num, double inlier_thresh, int64_t min_num,
     int64_t max_num, std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection, int64_t seed,
-    int64_t singular_policy, int64_t first_image, int64_t count_kernel)
+    int64_t singular_policy, int64_t first_image, int64_t count_kernel, std::optional<at::Tensor> status,
+    std::optional<int64_t> cap)
 {
     const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num,
                                  singular_policy, seed);
     p.first_image = (int32_t)first_image;
     p.count_kernel = (int32_t)count_kernel;
+    if (status.has_value()) {                               // per-image PVV_STATUS_* bits (e.g. list truncated at cap)
+        check_dev(*status, "status", at::kInt);
+        same_device(vertex, *status, "status");
+        TORCH_CHECK(status->dim() == 1 && status->size(0) == p.B, "status must be [b]");
+        p.d_status = status->data_ptr<int32_t>();
+    }
     cap_for_selection(selection, p);
+    if (cap.has_value()) {                                  // rows reserved per image (default: pvv_default_cap)
+        TORCH_CHECK(*cap >= 1 && *cap <= (int64_t)p.H * p.W, "cap must be in [1, h*w]");
+        p.cap = (int32_t)*cap;
+    }
     const int32_t *ip = opt_idxs(idxs, vertex, p);
     const float *sp = opt_selection(selection, vertex, p);
     at::Tensor ws = make_workspace(p, vertex);
@@ -266,7 +277,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> ransac_voting_v3(
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_v3(
     at::Tensor seg, at::Tensor vertex, int64_t round_hyp_num, double inlier_thresh, int64_t min_num, int64_t max_num,
     std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection, int64_t seed, int64_t singular_policy,
-    int64_t first_image)
+    int64_t first_image, int64_t count_kernel)
 {
     const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     TORCH_CHECK(seg.is_cuda(), "seg must be a CUDA tensor");
@@ -277,6 +288,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_v3(
     auto mask = at::empty({seg.size(0), seg.size(2), seg.size(3)}, seg.options().dtype(at::kLong));
     pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, singular_policy, seed);
     p.first_image = (int32_t)first_image;
+    p.count_kernel = (int32_t)count_kernel;
     p.seg_classes = (int32_t)seg.size(1);
     for (int i = 0; i < 4; ++i) p.seg_stride[i] = seg.stride(i);
     cap_for_selection(selection, p);
@@ -411,13 +423,71 @@ std::vector<double> count_kernel_ms_in_pipeline(std::vector<at::Tensor> masks, s
     return ms;
 }
 
+// `reps` full ransac_voting_layer_v3 calls cycling over the given batches with a HIP event at every stage boundary
+// (pvv_problem.ev_marks) -> per call the PVV_N_MARKS - 1 durations in ms: [scan, compact+hyp, count pass, select_refit,
+// finalize, (staged only:) first count launch, first prune, 0].  One synchronisation at the end; a measurement aid.
+std::vector<std::vector<double>> stage_ms_in_pipeline(std::vector<at::Tensor> masks, std::vector<at::Tensor> vertices,
+                                                      int64_t round_hyp_num, double inlier_thresh, int64_t min_num,
+                                                      int64_t max_num, int64_t seed, int64_t reps, int64_t count_kernel)
+{
+    TORCH_CHECK(!masks.empty() && masks.size() == vertices.size(), "need as many masks as vertex fields");
+    const c10::DeviceGuard device_guard(vertices[0].device());
+    std::vector<hipEvent_t> ev((size_t)PVV_N_MARKS * (size_t)reps);
+    for (auto &e : ev) TORCH_CHECK(hipEventCreate(&e) == hipSuccess, "hipEventCreate failed");
+    std::vector<at::Tensor> keep;
+    for (int64_t r = 0; r < reps; ++r) {
+        const at::Tensor &mask = masks[r % masks.size()], &vertex = vertices[r % masks.size()];
+        pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, PVV_SINGULAR_REFERENCE,
+                                     seed + r);
+        p.count_kernel = (int32_t)count_kernel;
+        p.ev_marks = (void **)&ev[(size_t)PVV_N_MARKS * (size_t)r];
+        at::Tensor ws = make_workspace(p, vertex);
+        auto out = at::empty({p.B, p.K, 2}, vertex.options());
+        ok(pvv_ransac_voting_v3(&p, mask.data_ptr(), vertex.data_ptr<float>(), nullptr, nullptr, ws.data_ptr(),
+                                (size_t)ws.numel(), out.data_ptr<float>(), nullptr, nullptr, cur_stream(vertex)),
+           "ransac_voting_v3");
+        keep.push_back(ws);
+        keep.push_back(out);
+    }
+    TORCH_CHECK(hipStreamSynchronize((hipStream_t)cur_stream(vertices[0])) == hipSuccess, "hipStreamSynchronize failed");
+    std::vector<std::vector<double>> ms((size_t)reps, std::vector<double>(PVV_N_MARKS - 1, 0.0));
+    for (int64_t r = 0; r < reps; ++r) {
+        hipEvent_t *e = &ev[(size_t)PVV_N_MARKS * (size_t)r];
+        auto dt = [&](int a, int b) {
+            float t = 0.f;
+            return hipEventElapsedTime(&t, e[a], e[b]) == hipSuccess ? (double)t : -1.0;   // -1: a mark that was not recorded
+        };
+        ms[(size_t)r][0] = dt(PVV_MARK_BEGIN, PVV_MARK_SCAN);
+        ms[(size_t)r][1] = dt(PVV_MARK_SCAN, PVV_MARK_COMPACT);
+        ms[(size_t)r][2] = dt(PVV_MARK_COMPACT, PVV_MARK_COUNT);
+        ms[(size_t)r][3] = dt(PVV_MARK_COUNT, PVV_MARK_SELECT);
+        ms[(size_t)r][4] = dt(PVV_MARK_SELECT, PVV_MARK_END);
+        ms[(size_t)r][5] = dt(PVV_MARK_COMPACT, PVV_MARK_STAGE0);
+        ms[(size_t)r][6] = dt(PVV_MARK_STAGE0, PVV_MARK_PRUNE0);
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return ms;
+}
+
+// SURVEY 8(d)'s streaming-read microbenchmark: one read-once pass over `buf` (pvv_stream_read_probe); the caller brackets
+// it with events
+void stream_read_probe(at::Tensor buf, at::Tensor sink)
+{
+    const c10::DeviceGuard device_guard(buf.device());
+    TORCH_CHECK(buf.is_cuda() && buf.is_contiguous() && sink.is_cuda() && sink.scalar_type() == at::kInt && sink.numel() >= 1,
+                "stream_read_probe: contiguous CUDA buffer and an int32 CUDA sink");
+    const size_t bytes = ((size_t)buf.numel() * buf.element_size()) & ~(size_t)15;
+    ok(pvv_stream_read_probe(buf.data_ptr(), bytes, (uint32_t *)sink.data_ptr<int32_t>(), cur_stream(buf)), "stream_read_probe");
+}
+
 // Re-run only the inlier-count kernel on the state a previous ransac_voting_v3 call left in `ws`
 // (bench.py brackets this with HIP events to get the dominant kernel's duration).
 void rerun_count_kernel(at::Tensor mask, at::Tensor vertex, int64_t hn, double inlier_thresh, int64_t min_num,
-                        int64_t max_num, at::Tensor ws, bool zero_counts)
+                        int64_t max_num, at::Tensor ws, bool zero_counts, int64_t count_kernel)
 {
     const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     pvv_problem p = make_problem(mask, vertex, hn, inlier_thresh, min_num, max_num, 0, 0);
+    p.count_kernel = (int32_t)count_kernel;
     check_dev(ws, "workspace", at::kByte);
     ok(pvv_rerun_count_kernel(&p, ws.data_ptr(), (size_t)ws.numel(), zero_counts ? 1 : 0, cur_stream(vertex)),
        "rerun_count_kernel");
@@ -442,11 +512,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("ransac_voting_v3", &ransac_voting_v3, "batched ransac_voting_layer_v3", py::arg("mask"), py::arg("vertex"),
           py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"), py::arg("idxs"),
           py::arg("selection"), py::arg("seed"), py::arg("singular_policy"), py::arg("first_image") = 0,
-          py::arg("count_kernel") = 0);
+          py::arg("count_kernel") = 0, py::arg("status") = py::none(), py::arg("cap") = py::none());
     m.def("decode_keypoint_v3", &decode_keypoint_v3, "argmax(seg) fused with batched ransac_voting_layer_v3",
           py::arg("seg"), py::arg("vertex"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"),
           py::arg("max_num"), py::arg("idxs"), py::arg("selection"), py::arg("seed"), py::arg("singular_policy"),
-          py::arg("first_image") = 0);
+          py::arg("first_image") = 0, py::arg("count_kernel") = 0);
     m.def("decode_keypoint_un_pnp", &decode_keypoint_un_pnp,
           "argmax(seg) + ransac_voting_layer_v3 + estimate_voting_distribution_with_mean in one pass (two-class seg)",
           py::arg("seg"), py::arg("vertex"), py::arg("round_hyp_num"), py::arg("hyp_est"), py::arg("inlier_thresh"),
@@ -456,7 +526,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           "batched estimate_voting_distribution_with_mean", py::arg("mask"), py::arg("vertex"), py::arg("mean"),
           py::arg("hyp_total"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"), py::arg("idxs"),
           py::arg("selection"), py::arg("seed"), py::arg("want_hyp"), py::arg("first_image") = 0, py::arg("count_kernel") = 0);
-    m.def("rerun_count_kernel", &rerun_count_kernel, "re-launch the inlier-count kernel (profiling aid)");
+    m.def("rerun_count_kernel", &rerun_count_kernel, "re-launch the inlier-count pass (profiling aid)", py::arg("mask"),
+          py::arg("vertex"), py::arg("hn"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"), py::arg("ws"),
+          py::arg("zero_counts"), py::arg("count_kernel") = 0);
+    m.def("stage_ms_in_pipeline", &stage_ms_in_pipeline,
+          "per-stage durations inside full v3 calls, HIP events at the stage boundaries (profiling aid)", py::arg("masks"),
+          py::arg("vertices"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"),
+          py::arg("seed"), py::arg("reps"), py::arg("count_kernel") = 0);
+    m.def("stream_read_probe", &stream_read_probe, "one read-once streaming pass over a buffer (bench aid)");
     m.def("count_kernel_ms_in_pipeline", &count_kernel_ms_in_pipeline,
           "duration of the inlier-count kernel inside full v3 calls, HIP events around its launch (profiling aid)",
           py::arg("masks"), py::arg("vertices"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"),
@@ -467,4 +544,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.attr("SINGULAR_IMAGE_ZERO") = (int)PVV_SINGULAR_IMAGE_ZERO;
     m.attr("COUNT_AUTO") = (int)PVV_COUNT_AUTO;
     m.attr("COUNT_EXACT") = (int)PVV_COUNT_EXACT;
+    m.attr("COUNT_FULL") = (int)PVV_COUNT_FULL;
+    m.attr("COUNT_STAGED") = (int)PVV_COUNT_STAGED;
+    m.attr("STATUS_SKIPPED") = (int)PVV_STATUS_SKIPPED;
+    m.attr("STATUS_SUBSAMPLED") = (int)PVV_STATUS_SUBSAMPLED;
+    m.attr("STATUS_TRUNCATED") = (int)PVV_STATUS_TRUNCATED;
 }

@@ -19,6 +19,13 @@ def shard_bounds(batch, world_size, rank):
     return lo, min(batch, lo + per)
 
 
+class _Done:
+    """Work handle of a collective that has already completed (the host-staged gloo path)."""
+
+    def wait(self):
+        return True
+
+
 def gather_results(local, batch, group=None, async_op=False):
     """all_gather per-image results ``[b_local, ...]`` -> ``[batch, ...]`` on every rank, in batch order.
 
@@ -38,6 +45,15 @@ def gather_results(local, batch, group=None, async_op=False):
     else:
         pad = local.new_zeros((per,) + tuple(local.shape[1:]))
         pad[: hi - lo] = local
+    if pad.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo moves host memory: stage the (72 B/image) results through the host.  Only met when ranks share a GPU --
+        # RCCL refuses two ranks on one device -- i.e. in the two-ranks-on-one-GPU tests; on a node with a GPU per rank the
+        # backend is nccl (= RCCL) and the branch below runs.
+        host = pad.cpu()
+        out_h = host.new_empty((world * per,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out_h, host, group=group)
+        out = out_h.to(local.device)
+        return (out[:batch], _Done()) if async_op else out[:batch]
     out = local.new_empty((world * per,) + tuple(local.shape[1:]))
     work = dist.all_gather_into_tensor(out, pad, group=group, async_op=async_op)
     return (out[:batch], work) if async_op else out[:batch]

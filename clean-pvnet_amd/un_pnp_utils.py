@@ -58,14 +58,33 @@ def rotation_to_angle_axis(R):
     return v / (2 * np.sin(th)) * th
 
 
-def initial_pose_dlt(points_3d, points_2d, camera_matrix):
+def initial_pose_dlt(points_3d, points_2d, camera_matrix, order_key=None):
     """Pose from >= 6 non-coplanar correspondences by the direct linear transform, rotation orthogonalised by SVD.
-    -> rt [6] (angle-axis, translation).  Used when OpenCV's P3P is not importable."""
+    -> rt [6] (angle-axis, translation).  Used when OpenCV's P3P is not importable.
+
+    ``order_key`` [pn] (the reference's ``weights_2d[:,0] + weights_2d[:,1]``, un_pnp_utils.py:26) makes the start follow
+    the reference's selection -- it seeds from its best-weighted keypoints only --: keypoints without weight (occluded /
+    high-variance votes, weight 0) are left out as long as six remain, and the rows of the others are scaled by the square
+    root of their relative key, so that one gross outlier with no weight cannot push the start out of the basin of the
+    refinement."""
     P = np.asarray(points_3d, np.float64)
     p = np.asarray(points_2d, np.float64)
     pn = P.shape[0]
     if pn < 6:
         raise NotImplementedError("the DLT start needs >= 6 keypoints; with 4-5 install OpenCV (SOLVEPNP_P3P, as the reference)")
+    row_w = np.ones(pn)
+    if order_key is not None:
+        key = np.where(np.isfinite(order_key), np.asarray(order_key, np.float64), 0.0)
+        key = np.clip(key, 0.0, None)
+        keep = key > 0
+        if keep.sum() < 6:                                      # too few weighted keypoints: the six best-weighted
+            keep = np.zeros(pn, bool)
+            keep[np.argsort(-key, kind="stable")[:6]] = True
+            key = np.where(key > 0, key, 0.0) + 1e-12
+        P, p, key = P[keep], p[keep], key[keep]
+        pn = P.shape[0]
+        row_w = np.sqrt(key / key.max())
+        row_w = np.maximum(row_w, 1e-3)
     Kinv = np.linalg.inv(np.asarray(camera_matrix, np.float64))
     n = (Kinv @ np.concatenate([p, np.ones((pn, 1))], 1).T).T                 # normalised image points
     c = P.mean(0)
@@ -77,6 +96,7 @@ def initial_pose_dlt(points_3d, points_2d, camera_matrix):
     A[0::2, 8:12] = -n[:, :1] * Qh
     A[1::2, 4:8] = Qh
     A[1::2, 8:12] = -n[:, 1:2] * Qh
+    A *= np.repeat(row_w, 2)[:, None]
     M = np.linalg.svd(A)[2][-1].reshape(3, 4)
     if np.linalg.det(M[:, :3]) < 0:
         M = -M
@@ -89,11 +109,84 @@ def initial_pose_dlt(points_3d, points_2d, camera_matrix):
     return np.concatenate([rotation_to_angle_axis(R), t])
 
 
+def p3p_depths(f, P):
+    """Grunert's perspective-three-point solution: unit bearings ``f`` [3,3] of the object points ``P`` [3,3] -> the (up
+    to four) depth triples (s1, s2, s3) with ``|s_i f_i - s_j f_j| = |P_i - P_j|``.  With s2 = u s1, s3 = v s1 the three
+    cosine-law equations reduce to a quartic in v (Haralick et al., "Review and analysis of solutions of the three point
+    perspective pose estimation problem", 1994, eqs. 9-11)."""
+    a2 = float(((P[1] - P[2]) ** 2).sum()); b2 = float(((P[0] - P[2]) ** 2).sum()); c2 = float(((P[0] - P[1]) ** 2).sum())
+    if min(a2, b2, c2) <= 0:
+        return []
+    ca, cb, cg = float(f[1] @ f[2]), float(f[0] @ f[2]), float(f[0] @ f[1])
+    q, r = (a2 - c2) / b2, (a2 + c2) / b2
+    coef = [(q - 1) ** 2 - 4 * c2 / b2 * ca ** 2,
+            4 * (q * (1 - q) * cb - (1 - r) * ca * cg + 2 * c2 / b2 * ca ** 2 * cb),
+            2 * (q ** 2 - 1 + 2 * q ** 2 * cb ** 2 + 2 * ((b2 - c2) / b2) * ca ** 2 - 4 * r * ca * cb * cg + 2 * ((b2 - a2) / b2) * cg ** 2),
+            4 * (-q * (1 + q) * cb + 2 * a2 / b2 * cg ** 2 * cb - (1 - r) * ca * cg),
+            (1 + q) ** 2 - 4 * a2 / b2 * cg ** 2]
+    if not np.isfinite(coef).all():
+        return []
+    sols = []
+    for v in np.roots(coef):
+        if abs(v.imag) > 1e-6 * max(1.0, abs(v)) or v.real <= 0:
+            continue
+        v = float(v.real)
+        den = 2 * (cg - v * ca)
+        if abs(den) < 1e-14:
+            continue
+        u = ((q - 1) * v * v - 2 * q * cb * v + 1 + q) / den
+        d = 1 + u * u - 2 * u * cg
+        if u <= 0 or d <= 0:
+            continue
+        s1 = np.sqrt(c2 / d)
+        sols.append((s1, u * s1, v * s1))
+    return sols
+
+
+def initial_pose_p3p(points_3d, points_2d, camera_matrix, order_key):
+    """The reference's start (un_pnp_utils.py:26-32: ``cv2.solvePnP(..., SOLVEPNP_P3P)`` on the four best-weighted
+    keypoints) without OpenCV: P3P on the first three of those four, the fourth picks among the (up to four) solutions by
+    its reprojection error -- what OpenCV's P3P does with its fourth point.  -> rt [6] or None when no solution exists
+    (collinear points, a keypoint behind the camera)."""
+    P = np.asarray(points_3d, np.float64)
+    p = np.asarray(points_2d, np.float64)
+    Kc = np.asarray(camera_matrix, np.float64)
+    key = np.where(np.isfinite(order_key), np.asarray(order_key, np.float64), -np.inf)
+    idxs = np.argsort(key)[-4:]                                                # un_pnp_utils.py:26 / :88
+    P4, p4 = P[idxs], p[idxs]
+    n = (np.linalg.inv(Kc) @ np.concatenate([p4, np.ones((4, 1))], 1).T).T
+    f = n / np.linalg.norm(n, axis=1, keepdims=True)
+    best = None
+    for s in p3p_depths(f[:3], P4[:3]):
+        X = f[:3] * np.asarray(s)[:, None]                                     # the three points in the camera frame
+        cP, cX = P4[:3].mean(0), X.mean(0)
+        # absolute orientation of three points: rotation that maps the (centred) object triangle onto the camera one
+        H = (P4[:3] - cP).T @ (X - cX)
+        U, _S, Vt = np.linalg.svd(H)
+        D = np.diag([1.0, 1.0, np.sign(np.linalg.det(Vt.T @ U.T)) or 1.0])
+        R = Vt.T @ D @ U.T
+        t = cX - R @ cP
+        x4 = R @ P4[3] + t
+        if x4[2] <= 0:
+            continue
+        proj = Kc @ (x4 / x4[2])
+        err = float(((proj[:2] - p4[3]) ** 2).sum())
+        if best is None or err < best[0]:
+            best = (err, R, t)
+    if best is None:
+        return None
+    return np.concatenate([rotation_to_angle_axis(best[1]), best[2]])
+
+
 def _initial_pose(points_3d, points_2d, camera_matrix, order_key):
     try:
         import cv2
     except ImportError:
-        return initial_pose_dlt(points_3d, points_2d, camera_matrix), None
+        # no OpenCV in this image: the same selection and the same solver family in numpy; the DLT only as the fallback
+        rt = initial_pose_p3p(points_3d, points_2d, camera_matrix, order_key)
+        if rt is not None:
+            return rt, (rt[:3].reshape(3, 1), rt[3:].reshape(3, 1))
+        return initial_pose_dlt(points_3d, points_2d, camera_matrix, order_key), None
     try:
         dist_coeffs = uncertainty_pnp.dist_coeffs
     except AttributeError:

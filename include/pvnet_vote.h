@@ -30,7 +30,7 @@ extern "C" {
 #define PVV_E_WORKSPACE (-2) /* workspace smaller than pvv_workspace_bytes() */
 
 /* ABI version of this header; pvv_abi_version() must return the same. */
-#define PVV_ABI_VERSION 5
+#define PVV_ABI_VERSION 6
 
 int pvv_abi_version(void);
 const char *pvv_last_error(void);
@@ -117,7 +117,32 @@ typedef struct pvv_problem {
     void *ev_count_end;      /* after the inlier-count launch of THIS call: the dominant kernel's duration as it runs
                                 inside the pipeline (a measurement aid: tools/count_kernel_timing.py compares it with
                                 re-launches of the kernel alone, a differential measurement and rocprofv3) */
+    /* ---- ABI v6 ---- */
+    int32_t *d_status;       /* optional DEVICE buffer [B] i32 (NULL = off): PVV_STATUS_* bits per image, written with tn.
+                                The one condition a caller cannot see otherwise is PVV_STATUS_TRUNCATED: the subsample of
+                                P:135-138 came out longer than the `cap` rows reserved (beyond 8 sigma with
+                                pvv_default_cap) and was cut */
+    void **ev_marks;         /* optional HOST array of PVV_N_MARKS hipEvent_t (NULL = off; NULL entries are skipped):
+                                recorded on `stream` at the stage boundaries of THIS call (PVV_MARK_*), so that every
+                                kernel's duration can be read as it runs inside the pipeline (bench.py's per-kernel
+                                rooflines).  A measurement aid: the records cost ~1 us each */
 } pvv_problem;
+
+/* pvv_problem.d_status bits */
+#define PVV_STATUS_SKIPPED 1     /* foreground_num < min_num: the image's keypoints are zeros (P:129-132 / P:211-216) */
+#define PVV_STATUS_SUBSAMPLED 2  /* foreground_num > max_num: pixels were kept with probability max_num/foreground_num  */
+#define PVV_STATUS_TRUNCATED 4   /* more rows than `cap`: the list was cut at cap rows (results are those of the cut list) */
+
+/* pvv_problem.ev_marks indices: the event is recorded AFTER the named stage has been enqueued */
+#define PVV_MARK_BEGIN 0    /* before the first kernel of the call                                    */
+#define PVV_MARK_SCAN 1     /* k_tile_scan (+ k_tile_subsample)                                       */
+#define PVV_MARK_COMPACT 2  /* k_compact_hyp                                                          */
+#define PVV_MARK_COUNT 3    /* the whole inlier-count pass (every stage and k_prune when staged)      */
+#define PVV_MARK_SELECT 4   /* k_select_refit (v3)                                                    */
+#define PVV_MARK_END 5      /* k_finalize_v3 / k_covariance: the call is complete                     */
+#define PVV_MARK_STAGE0 6   /* staged count only: the first k_count_bf16 launch                       */
+#define PVV_MARK_PRUNE0 7   /* staged count only: the first k_prune                                   */
+#define PVV_N_MARKS 8
 
 /* pvv_problem.count_kernel.  AUTO: the split-bf16 matrix-core prefilter with its guard band wherever it is valid
  * (0.5 <= inlier_thresh <= 0.99995, H and W <= 16384), the exact kernel elsewhere.  EXACT: the reference's own
@@ -125,6 +150,16 @@ typedef struct pvv_problem {
  * against.  (Round 1 selected this with an environment variable; the library now reads no environment.) */
 #define PVV_COUNT_AUTO 0
 #define PVV_COUNT_EXACT 1
+/* ABI v6.  ransac_voting_layer_v3 keeps only the arg-max of the counts (P:160-167), so pvv_ransac_voting_v3 /
+ * pvv_decode_keypoint_v3 may count in STAGES: every hypothesis over a spread quarter of the pixels, then only the
+ * hypotheses that can still reach a leader's exactly known full count over the rest (k_prune).  Winner, first-index
+ * tie rule, winner count and refit are bit-identical to the full pass; what differs is that the counters of eliminated
+ * hypotheses hold partial counts (they are not an output of v3).  AUTO stages when the batch is large enough for the
+ * two extra launches to pay; FULL = the matrix-core kernel over everything, never staged; STAGED = staged wherever the
+ * matrix-core kernel is valid (what the tests force at every size).  The estimate and the fused un_pnp pass weigh every
+ * hypothesis and always count in full. */
+#define PVV_COUNT_FULL 2
+#define PVV_COUNT_STAGED 3
 
 /* b_inv (P:97-109) falls back to the identity for the WHOLE image when the
  * batched solve raises; REFERENCE reproduces that (x = ATb for every keypoint
@@ -222,11 +257,20 @@ int pvv_decode_keypoint_un_pnp(const pvv_problem *p, int32_t hn_est, const float
                                float *d_weights, int32_t *d_win_counts, int32_t *d_tn,
                                void *stream);
 
+/* Bench aid: SURVEY 8(d)'s "achievable number from a streaming-read microbenchmark on the box".  Reads `bytes` (a
+ * multiple of 16) of d_buf once with 16-byte loads per lane from a persistent grid and writes a 4-byte checksum to
+ * d_sink (so the loads cannot be elided); bracket it with events on `stream`.  Nothing of the voting path uses it. */
+int pvv_stream_read_probe(const void *d_buf, size_t bytes, uint32_t *d_sink, void *stream);
+
 /* Bench / profiling aid: re-runs ONLY the inlier-count kernel of the last
  * layer call recorded in `d_workspace` (same problem), so its duration can be
  * bracketed with HIP events on `stream`.  zero_counts != 0 first clears the
  * counters (a separate memset node) so the result stays valid; with 0 nothing
- * but the kernel is enqueued and the counters keep accumulating. */
+ * but the kernel is enqueued and the counters keep accumulating.  When the
+ * problem counts in stages (see PVV_COUNT_STAGED) and zero_counts is 1, the
+ * whole pass is re-run -- every stage and k_prune; with zero_counts = 0 the
+ * FULL kernel runs (the elimination compares partial counts, so it needs
+ * cleared counters), and an explicit PVV_COUNT_STAGED is refused then. */
 int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace,
                            size_t workspace_bytes, int zero_counts,
                            void *stream);

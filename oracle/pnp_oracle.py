@@ -93,13 +93,16 @@ def solve_lm(init_rt, pts2d, pts3d, wgt2d, K, max_iterations=50):
         r = r.reshape(-1)
         return 0.5 * float(r @ r), J.T @ J, J.T @ r
     c, A, g = ev(x)
+    # Ceres: Jacobi scaling 1/(1 + |J_i|) from the initial point; LM diagonal = squared norm of the scaled column clamped to
+    # [min_lm_diagonal, max_lm_diagonal] = [1e-6, 1e32] (levenberg_marquardt_strategy.cc)
+    s2 = (1.0 / (1.0 + np.sqrt(np.diag(A)))) ** 2
     info = dict(initial_cost=c, termination=0)
     it = 0
     while it < max_iterations:
         if np.abs(g).max() <= 1e-10:
             info["termination"] = 1
             break
-        d = np.clip(np.sqrt(np.diag(A)), 1e-6, 1e32) ** 2 / radius
+        d = np.clip(np.diag(A) * s2, 1e-6, 1e32) / (s2 * radius)
         try:
             step = np.linalg.solve(A + np.diag(d), -g)
             ok = bool(np.all(np.linalg.eigvalsh(A + np.diag(d)) > 0))

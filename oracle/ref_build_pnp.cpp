@@ -73,6 +73,8 @@ void Solve(const Solver::Options &o, Problem *problem, Solver::Summary *summary)
     double JtJ[36], g[6], radius = o.initial_trust_region_radius, decrease = 2.0;
     double cost = evaluate(*problem, x, JtJ, g);
     summary->initial_cost = cost;
+    double s2[6];                        // Jacobi scaling of the initial point, squared: 1 / (1 + |J_i|)^2
+    for (int i = 0; i < n; ++i) { const double sc = 1.0 / (1.0 + std::sqrt(JtJ[i * n + i])); s2[i] = sc * sc; }
     const int max_iter = g_max_iter >= 0 ? g_max_iter : o.max_num_iterations;
     int it = 0;
     summary->termination = 0;
@@ -82,9 +84,8 @@ void Solve(const Solver::Options &o, Problem *problem, Solver::Summary *summary)
         if (gmax <= o.gradient_tolerance) { summary->termination = 1; break; }
         double d[6], step[6], neg_g[6];
         for (int i = 0; i < n; ++i) {
-            double di = std::sqrt(JtJ[i * n + i]);
-            di = std::fmin(std::fmax(di, o.min_lm_diagonal), o.max_lm_diagonal);
-            d[i] = di * di / radius;
+            const double di = std::fmin(std::fmax(JtJ[i * n + i] * s2[i], o.min_lm_diagonal), o.max_lm_diagonal);
+            d[i] = di / (s2[i] * radius);
             neg_g[i] = -g[i];
         }
         bool ok = chol_solve(JtJ, d, neg_g, step, n);

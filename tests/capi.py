@@ -20,7 +20,8 @@ class Problem(ctypes.Structure):
                 ("singular_policy", c_i32), ("inlier_thresh", c_f32),
                 ("mask_stride", c_i64 * 3), ("vertex_stride", c_i64 * 5), ("seed", c_u64),
                 ("seg_classes", c_i32), ("first_image", c_i32), ("seg_stride", c_i64 * 4),
-                ("count_kernel", c_i32), ("reserved0", c_i32), ("d_draws_out", vp), ("ev_count_begin", vp), ("ev_count_end", vp)]
+                ("count_kernel", c_i32), ("reserved0", c_i32), ("d_draws_out", vp), ("ev_count_begin", vp), ("ev_count_end", vp),
+                ("d_status", vp), ("ev_marks", vp)]
 
 
 def declared_symbols():
@@ -53,12 +54,13 @@ def load():
         L.pvv_estimate_voting_distribution.argtypes = [ctypes.POINTER(Problem), vp, vp, vp, vp, vp, vp, sz,
                                                        vp, vp, vp, vp, vp, vp]
         L.pvv_rerun_count_kernel.argtypes = [ctypes.POINTER(Problem), vp, sz, ctypes.c_int, vp]
+        L.pvv_stream_read_probe.argtypes = [vp, sz, vp, vp]
         _lib = L
     return _lib
 
 
 def problem(mask, vertex, hn, thresh, min_num=5, max_num=30000, policy=0, seed=0, count_kernel=0, draws_out=None,
-            first_image=0, cap=None):
+            first_image=0, cap=None, status=None):
     L = load()
     p = Problem()
     p.B, p.H, p.W, p.K, _ = vertex.shape
@@ -69,6 +71,7 @@ def problem(mask, vertex, hn, thresh, min_num=5, max_num=30000, policy=0, seed=0
     p.count_kernel = count_kernel
     p.first_image = first_image
     p.d_draws_out = None if draws_out is None else draws_out.data_ptr()
+    p.d_status = None if status is None else status.data_ptr()
     p.singular_policy = policy
     p.inlier_thresh = thresh
     p.mask_stride[:] = mask.stride()

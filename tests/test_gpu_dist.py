@@ -75,3 +75,83 @@ def test_hip_layer_under_a_one_rank_nccl_group_equals_the_unsharded_call(gpu):
     assert res["backend"] == "nccl"
     assert res["equal"] and res["split_equal"] and res["cov_equal"]
     assert res["shape"] == [5, 4, 2] and res["empty"] == [0, 4, 2] and res["err"] < 10
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A world of TWO ranks on the ONE GPU the box has.  RCCL refuses two ranks on one device, so the ranks
+# exchange over gloo (clean_pvnet_amd.dist stages the 72 B/image results through the host); everything else -- shard
+# bounds, the common RNG key, uneven and empty shards, padding inside gather_results, the HIP layer itself -- is the code
+# an 8-GPU run executes.
+# ---------------------------------------------------------------------------------------------------------------------
+_TWO_RANKS = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import lib; lib._register_clean_pvnet_amd()
+from clean_pvnet_amd import dist as pdist, synth
+from lib.csrc.ransac_voting.ransac_voting_gpu import ransac_voting_layer_v3, estimate_voting_distribution_with_mean
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", 0)                      # both ranks on the one GPU
+torch.cuda.set_device(dev)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+res = {}
+for name, batch, cfgname in (("b5", 5, "cfg1"), ("b1", 1, "cfg1"), ("b3_480x640", 3, "cfg2")):
+    c = {**synth.CONFIGS[cfgname], "B": batch}
+    hn = c["hn"]
+    d = synth.make_batch(**c, device=dev)          # every rank can make the whole batch: images depend on their index only
+    lo, hi = pdist.shard_bounds(batch, world, rank)
+    got = pdist.sharded_vote(ransac_voting_layer_v3, d["mask"][lo:hi], d["vertex"][lo:hi], batch, hn, inlier_thresh=0.99, seed=4242)
+    want = ransac_voting_layer_v3(d["mask"], d["vertex"], hn, inlier_thresh=0.99, seed=4242)       # unsharded HIP call
+    mean, cov = estimate_voting_distribution_with_mean(d["mask"][lo:hi], d["vertex"][lo:hi], want[lo:hi], seed=7, first_image=lo)
+    cov_all = pdist.gather_results(cov, batch)
+    _m, cov_want = estimate_voting_distribution_with_mean(d["mask"], d["vertex"], want, seed=7)
+    res[name] = dict(shard=[lo, hi], equal=bool(torch.equal(got, want)), cov_equal=bool(torch.equal(cov_all, cov_want)),
+                     shape=list(got.shape), err=float((got - d["kpt_2d"]).abs().max()))
+torch.cuda.synchronize()
+print("RESULT " + json.dumps(dict(rank=rank, world=dist.get_world_size(), backend=dist.get_backend(), res=res)), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+""" % ROOT
+
+
+def test_hip_layer_in_a_world_of_two_ranks_on_one_gpu_uneven_shards(gpu, tmp_path):
+    """5 images / 2 ranks (3 + 2), 1 image / 2 ranks (1 + 0: the second rank enters the collective with zero rows) and
+    3 full-size images (2 + 1): sharded HIP calls + gather == the unsharded HIP call, bit for bit, on every rank -- means
+    from ransac_voting_layer_v3 and covariances from the estimate (device RNG keyed by the global image index)."""
+    script = tmp_path / "two_ranks.py"
+    script.write_text(_TWO_RANKS)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29535", str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=_env(), timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [json.loads(l.split("RESULT ", 1)[1]) for l in r.stdout.splitlines() if "RESULT " in l]
+    assert sorted(x["rank"] for x in lines) == [0, 1]
+    for x in lines:
+        assert x["world"] == 2 and x["backend"] == "gloo"
+        assert x["res"]["b5"]["shard"] == ([0, 3] if x["rank"] == 0 else [3, 5])
+        assert x["res"]["b1"]["shard"] == ([0, 1] if x["rank"] == 0 else [1, 1])
+        for name, shape in (("b5", [5, 4, 2]), ("b1", [1, 4, 2]), ("b3_480x640", [3, 9, 2])):
+            q = x["res"][name]
+            assert q["equal"] and q["cov_equal"] and q["shape"] == shape and q["err"] < 10, (name, q)
+
+
+def test_bare_bench_gpus_2_launches_its_own_ranks(gpu):
+    """`python bench.py --gpus 2 --steps 3` with NO launcher and no WORLD_SIZE (it used to die on an
+    assertion): bench.py starts its ranks under torch.distributed.run itself.  On this 1-GPU box the two ranks share the
+    device and exchange over gloo; shards of 3 + 2 images, weak-scaling and overlapped-exchange legs included."""
+    env = _env()
+    for k in ("WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "5",
+           "--rotate", "2", "--prewarm-ms", "20"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints, nobody else
+    line = json.loads(lines[0])
+    ex = line["extra"]
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong" and line["value"] > 0
+    assert ex["shard_sizes"] == [3, 2] and ex["collective_ranks"] == 2 and ex["backend"] == "gloo"
+    assert ex["oversubscribed_ranks_per_gpu"] == 2 and ex["rccl_ranks"] is None
+    assert len(ex["per_rank_count_kernel_ms"]) == 2 and all(x > 0 for x in ex["per_rank_count_kernel_ms"])
+    assert ex["known_answer_max_err_px"] < 20 and ex["weak_scaling_images_per_s"] > 0
+    assert "scaling_vs_n1_profile" in ex and line["cpu_baseline"] is None

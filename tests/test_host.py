@@ -31,7 +31,7 @@ def test_cabi_library_exports_every_declared_symbol():
 
 def test_cabi_version_and_cap_and_validation():
     L = capi.load()
-    assert L.pvv_abi_version() == 5
+    assert L.pvv_abi_version() == 6
     assert L.pvv_default_cap(480, 640, 30000) == 30000 + int(8 * 30000 ** 0.5) + 64
     assert L.pvv_default_cap(128, 128, 30000) == 128 * 128
     p = capi.Problem()
@@ -54,7 +54,7 @@ def test_extension_module_surface_matches_reference(pkg):
     for name in ("generate_hypothesis", "voting_for_hypothesis", "generate_hypothesis_vanishing_point",
                  "voting_for_hypothesis_vanishing_point"):                  # ransac_voting.cpp:102-107
         assert callable(getattr(ext, name))
-    assert ext.abi_version == 5
+    assert ext.abi_version == 6
     import lib.csrc.ransac_voting.ransac_voting as ref_path                  # ransac_voting_gpu.py:2
     assert ref_path.generate_hypothesis is ext.generate_hypothesis
 
@@ -185,3 +185,75 @@ def test_bench_line_contract_on_the_committed_evidence():
     assert c["kind"] in ("port", "reference") and c["unit"] == line["unit"]
     images = line["config"]["global_batch"] * line["steps"]
     assert abs(line["value"] - images / (line["ms_per_step"] * 1e-3 * line["steps"])) / line["value"] < 0.01
+
+
+def test_bare_bench_gpus_n_builds_the_torchrun_command(monkeypatch):
+    """`python bench.py --gpus 4` with no WORLD_SIZE re-launches itself under torch.distributed.run: the
+    command is the driver's own, rendezvous on 127.0.0.1, the original flags passed through."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert bench.relaunch_under_torchrun(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 1024
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # and main() takes that branch before touching a GPU
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+
+
+def _kernel_isa(asm, mangled_fragment):
+    """The ISA text of the kernel whose mangled name contains `mangled_fragment`, and its metadata block."""
+    import re
+    m = re.search(r"^(_ZN\S*%s\S*):[^\n]*\n(.*?)^\.Lfunc_end\d+:" % re.escape(mangled_fragment), asm, re.S | re.M)
+    assert m, "kernel %s not found in the ISA listing" % mangled_fragment
+    name, body = m.group(1), m.group(2)
+    pos = re.search(r"\.name:\s+%s\n" % re.escape(name), asm)
+    assert pos, "no metadata for %s" % name
+    start = asm.rfind("\n  - .", 0, pos.start())                      # the kernel's entry of amdhsa.kernels (YAML list item)
+    end = asm.find("\n  - .", pos.end())
+    return body, asm[start:end if end > 0 else len(asm)]
+
+
+def test_count_kernel_isa_guard(tmp_path):
+    """VERDICT r2 #2d / weak #9.  k_count_bf16 sits at the 96-register cliff (5 waves per SIMD): compile the translation
+    unit to gfx950 ISA with the shipped flags and assert, for BOTH instantiations (full and staged), 8 matrix-core
+    instructions, at most 96 VGPRs, and no scratch access between the first and the last of them (a spill inside the hot
+    loop would not fail any parity test, only the clock)."""
+    import re
+    import shutil
+    from importlib import util
+    spec = util.spec_from_file_location("_b", os.path.join(ROOT, "clean-pvnet_amd", "_build.py"))
+    b = util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    hipcc = shutil.which("hipcc") or os.path.join(b.ROCM, "bin", "hipcc")
+    out = tmp_path / "pvv.s"
+    flags = [f for f in b.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
+    subprocess.check_call([hipcc, *flags, "-I" + b.INCLUDE, "-I" + b.CSRC, "-S", "--cuda-device-only", "-o", str(out),
+                           os.path.join(b.CSRC, "pvnet_vote.hip")], stderr=subprocess.DEVNULL)
+    asm = out.read_text()
+    for frag in ("k_count_bf16ILb0E", "k_count_bf16ILb1E"):
+        body, meta = _kernel_isa(asm, frag)
+        lines = body.splitlines()
+        mf = [i for i, l in enumerate(lines) if "v_mfma_f32_32x32x16_bf16" in l]
+        assert len(mf) == 8, (frag, len(mf))
+        hot = "\n".join(lines[mf[0]:mf[-1] + 1])
+        assert not re.search(r"scratch_(load|store)|buffer_(load|store)_dword.*offen.*s\[0:3\]", hot), frag + ": scratch access inside the matrix-core loop"
+        assert "v_permlane32_swap" in body
+        vg = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
+        assert vg <= 96, (frag, vg)
+        lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", meta).group(1))
+        assert lds <= 32768, (frag, lds)                                # 5 blocks per CU in 160 KB
+    # the staged instantiation -- the one the headline benchmark runs -- holds no spilled vector register at all
+    _body, meta = _kernel_isa(asm, "k_count_bf16ILb1E")
+    assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1)) == 0

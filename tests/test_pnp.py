@@ -108,6 +108,49 @@ def test_dlt_start_is_inside_the_basin(pkg):
         np.testing.assert_allclose(rotation_to_angle_axis(rodrigues(w)), w, atol=1e-9)
 
 
+def test_dlt_start_ignores_a_gross_outlier_without_weight(pkg):
+    """an occluded keypoint voted far away carries weight 0 in the refinement (evaluators/linemod/pvnet.py:
+    121-125) -- the reference's P3P start never sees it (4 best-weighted points); the DLT start must not be dragged out of
+    the basin by it either.  The unweighted DLT over all points fails this (asserted, so the test keeps its teeth)."""
+    from clean_pvnet_amd.un_pnp_utils import initial_pose_dlt, initial_pose_p3p, rodrigues
+    bad_unweighted = 0
+    for seed in range(5):
+        p2, P, W, rt, _ = problem(seed, noise=0.5)
+        p2 = p2.copy(); W = W.copy()
+        p2[3] += np.array([180.0, -140.0])                    # one keypoint 230 px off ...
+        W[3] = 0.0                                            # ... which the uncertainty weights switch off
+        key = W[:, 0] + W[:, 1]
+        xs, _ = po.solve_scipy(rt, p2, P, W, KMAT)
+        init = initial_pose_p3p(P, p2, KMAT, key)             # the reference's start: its four best-weighted keypoints
+        assert init is not None
+        x, _info = po.solve_lm(init, p2, P, W, KMAT)
+        assert np.abs(rodrigues(x[:3]) - rodrigues(xs[:3])).max() < 1e-5 and np.abs(x[3:] - xs[3:]).max() < 1e-5
+        init0 = initial_pose_dlt(P, p2, KMAT)                 # unweighted DLT over all points (round 2's start)
+        bad_unweighted += int(np.abs(rodrigues(init0[:3]) - rodrigues(rt[:3])).max() > np.abs(rodrigues(init[:3]) - rodrigues(rt[:3])).max())
+    assert bad_unweighted >= 4                                # the P3P start is the closer one (nearly) every time
+
+
+def test_p3p_recovers_an_exact_pose_and_handles_four_and_five_keypoints(pkg):
+    """Noise-free correspondences: the P3P start IS the pose (1e-8); with 4 keypoints the drop-in returns it as the
+    reference does (un_pnp_utils.py:34-38), with 5 it refines (round 2 refused fewer than 6 without OpenCV)."""
+    from clean_pvnet_amd.un_pnp_utils import initial_pose_p3p, p3p_depths, rodrigues
+    for seed in range(8):
+        p2, P, W, rt, _ = problem(seed, noise=0.0)
+        init = initial_pose_p3p(P, p2, KMAT, W[:, 0] + W[:, 1])
+        assert init is not None
+        assert np.abs(rodrigues(init[:3]) - rodrigues(rt[:3])).max() < 1e-7 and np.abs(init[3:] - rt[3:]).max() < 1e-7
+        # every depth triple satisfies the three cosine-law equations
+        idx = np.argsort(W[:, 0] + W[:, 1])[-3:]
+        n = (np.linalg.inv(KMAT) @ np.concatenate([p2[idx], np.ones((3, 1))], 1).T).T
+        f = n / np.linalg.norm(n, axis=1, keepdims=True)
+        sols = p3p_depths(f, P[idx])
+        assert 1 <= len(sols) <= 4
+        for s in sols:
+            X = f * np.asarray(s)[:, None]
+            for i, j in ((0, 1), (0, 2), (1, 2)):
+                assert abs(np.linalg.norm(X[i] - X[j]) - np.linalg.norm(P[idx][i] - P[idx][j])) < 1e-9
+
+
 # ------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_gpu_batched_equals_the_lm_twin_and_reaches_the_minimum(pkg, gpu):

@@ -68,6 +68,8 @@ def exact_v3(oracle, mask, vertex, hn, thresh, idxs, selection=None, max_num=300
             sol.append((0.0, 0.0) if det == 0 else (float((yy * bx - xy * by) / det), float((xx * by - xy * bx) / det)))
         if singular == "reference" and any(sing):
             out[bi] = np.array(atb)
+        elif singular == "image_zero" and any(sing):      # the v1 layer: torch.inverse raises for the whole image (P:86-91)
+            out[bi] = 0.0
         else:
             out[bi] = np.array(sol)
     return out
