@@ -383,6 +383,17 @@ def main():
                             blk["traffic_source"] = "profiles/front_kernels_pmc.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
             except Exception:
                 pass
+        clock_ghz = torch.cuda.get_device_properties(dev).clock_rate / 1e6 if hasattr(torch.cuda.get_device_properties(dev), "clock_rate") else 2.4
+        peak_evals = N_SIMD * clock_ghz * 1e9 * EVALS_PER_TILE / (VALU_PER_TILE * CYCLES_PER_VALU)
+        ach_evals = evals / (k_avg_ms * 1e-3) if k_avg_ms else 0.0
+        roofline_valu = {"bound": "valu_issue", "achieved": round(ach_evals / 1e12, 3), "peak": round(peak_evals / 1e12, 3),
+                         "unit": "T evaluations/s", "frac": round(ach_evals / peak_evals, 4),
+                         "model": "%d SIMDs x %.2f GHz (device max clock) x %d evaluations per matrix-core tile / (%d VALU x %.1f "
+                                  "cycles): the steady-state loop with no prologue, no flagged tiles and no idle SIMD"
+                                  % (N_SIMD, clock_ghz, EVALS_PER_TILE, VALU_PER_TILE, CYCLES_PER_VALU),
+                         "note": ("EQUIVALENT evaluations of the full pass (B*K*hn*tn) per second: the staged pass reaches the same "
+                                  "winners with a fraction of them, so this can exceed 1") if staged_path else None}
+
         extra = {"tn_mean": round(float(tn_cpu.float().mean()), 1) if tn_cpu.numel() else 0.0,
                  "known_answer_max_err_px": round(err, 3),
                  "rotating_batches": len(batches), "bytes_per_batch_per_gpu": int(B * H * W * (8 + K * 8)),

@@ -455,7 +455,9 @@ std::vector<std::vector<double>> stage_ms_in_pipeline(std::vector<at::Tensor> ma
         hipEvent_t *e = &ev[(size_t)PVV_N_MARKS * (size_t)r];
         auto dt = [&](int a, int b) {
             float t = 0.f;
-            return hipEventElapsedTime(&t, e[a], e[b]) == hipSuccess ? (double)t : -1.0;   // -1: a mark that was not recorded
+            if (hipEventElapsedTime(&t, e[a], e[b]) == hipSuccess) return (double)t;
+            (void)hipGetLastError();       // a mark that was not recorded (not staged): clear the sticky error, report -1
+            return -1.0;
         };
         ms[(size_t)r][0] = dt(PVV_MARK_BEGIN, PVV_MARK_SCAN);
         ms[(size_t)r][1] = dt(PVV_MARK_SCAN, PVV_MARK_COMPACT);
