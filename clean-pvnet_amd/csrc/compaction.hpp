@@ -312,6 +312,7 @@ struct HypArgs {
     int32_t *draws_out;      // [B,K,hn,2] or null: the pixel (y*W+x) each index pair resolved to (tests)
     int blocks;              // hypothesis blocks per image
     int *surv;               // [B, kSurvCap] scratch: the survivors of a heavily subsampled image (see k_compact_hyp)
+    int *lead;               // [B,K,8] or null: leader counts of the staged count pass (count_prune.hpp); [4..7] zeroed here
 };
 
 constexpr int kHypRejectTries = 1 << 12;
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
         const int vi = gid / h.hn, hi = gid - vi * h.hn;
         const size_t o = ((size_t)b * v.K + vi) * h.hn + hi;
         h.counts[o] = 0;
+        if (h.lead && hi < 4) h.lead[((size_t)b * v.K + vi) * 8 + 4 + hi] = 0;
         if (tn <= 0) {
             h.hyps[o] = make_float2(0.f, 0.f);
             if (h.draws_out) { h.draws_out[2 * o] = -1; h.draws_out[2 * o + 1] = -1; }

@@ -64,7 +64,7 @@ __device__ __forceinline__ void split3(float x, __bf16 (&p)[3])
 //   (qx0,qy0,qx1,qx2,qx0,qy1,qy2,qy0 || qx0,qy0,qx1,qy1, 1,1,1,0),   q = pieces of h' = fl(h - o);
 // zeroes the hypothesis' LDS counter (flushed by the same thread later).  Returns 1 for a hypothesis that is non-finite
 // or astronomically far (the whole group then takes the exact loop).
-__device__ __forceinline__ int stage_hypothesis(bf16x8 *sB, int *sCnt, int i, float2 hp, float2 org)
+__device__ __forceinline__ int stage_hypothesis(bf16x8 *sB, int *sCnt, int i, float2 hp, float2 org, int cnt_init = 0)
 {
     __bf16 qx[3], qy[3];
     split3(hp.x - org.x, qx);
@@ -74,7 +74,7 @@ __device__ __forceinline__ int stage_hypothesis(bf16x8 *sB, int *sCnt, int i, fl
     const bf16x8 hi8 = {qx[0], qy[0], qx[1], qy[1], one, one, one, zero};
     sB[(i >> 5) * 64 + (i & 31)] = lo8;
     sB[(i >> 5) * 64 + 32 + (i & 31)] = hi8;
-    sCnt[i] = 0;
+    sCnt[i] = cnt_init;
     return !(fabsf(hp.x) < 1e15f && fabsf(hp.y) < 1e15f);
 }
 
@@ -97,36 +97,64 @@ __device__ __forceinline__ int stage_hypothesis(bf16x8 *sB, int *sCnt, int i, fl
 
 // ---------------------------------------------------------------------------------------------
 // Staged counting (ransac_voting_layer_v3 only): the layer needs the ARG-MAX of the counts and the winner's count
-// (P:160-167), not the counts.  A launch of k_count_bf16<true> counts only the 512-pixel chunks whose index has a residue
-// (mod M) in `mask`, and only the hypotheses that k_prune left alive: after stage s a hypothesis whose partial count plus
-// ALL pixels not yet counted stays below the exactly known full count of a leader can neither win nor tie and is dropped
-// (count_prune.hpp).  Survivors end with their exact full count, dropped ones with a partial count below the maximum:
-// winner, first-index tie rule and winner count are those of the full pass, bit for bit.
+// (P:160-167), not the counts.  Two launches instead of one:
+//   k_count_bf16<kCountFirst>   every hypothesis over the 512-pixel chunks whose index has a residue (mod M) in `mask`
+//                               -- a quarter of an image's chunks, spread over the object;
+//   k_lead (count_prune.hpp)    four leaders per (image, keypoint) counted EXACTLY over all the other pixels: L* = the
+//                               largest of four exactly known full counts;
+//   k_count_bf16<kCountFilter>  the other chunks, but only for hypotheses h with  partial(h) + R >= L*  (R = pixels not
+//                               counted by the first launch): every other hypothesis has full(h) <= partial(h) + R < L*
+//                               <= max and can neither win nor tie.  The filter is evaluated on the fly while a block
+//                               stages its hypotheses (count, bound and four leader numbers per (image, keypoint): no
+//                               survivor lists in memory); it reads counters that other blocks of the same launch are
+//                               adding to, which is benign: a dropped hypothesis is never counted, so its counter never
+//                               moves, and a kept one only grows -- the predicate is the same for every reader.
+// Kept hypotheses end with their exact full count, dropped ones with a partial count below the maximum: winner, first-index
+// tie rule and winner count are those of the full pass, bit for bit.  Images of fewer than n_min chunks are counted
+// completely by the first launch (nothing to gain from a bound taken after half of their pixels).
 // ---------------------------------------------------------------------------------------------
+enum { kCountFull = 0, kCountFirst = 1, kCountFilter = 2 };
+
+// The chunk schedule, compile-time (every index computation below is then shifts and constant multiplies; as run-time
+// parameters they were a dozen integer divisions per work item): the first launch counts the 512-pixel chunks c with
+// (c mod 8) in {1, 5} -- a quarter of the chunks, spread over the object (rows of the compacted list = raster order) --,
+// the second launch the other residues; images of fewer than kStageMinChunks chunks are counted completely by the first.
+constexpr int kStageM = 8;
+constexpr uint32_t kStageFirst = 0x22u, kStageRest = 0xffu & ~kStageFirst;
+constexpr int kStageMinChunks = 8;
+
 struct StageArgs {
-    uint32_t mask;        // residues (mod M) of the chunks this launch counts
-    int M;                // period of the chunk schedule (<= 31)
-    const float2 *hyp;    // [B,K,hn] the hypotheses this launch evaluates, dense from the front of every row
-    const int *idx;       // [B,K,hn] their indices in the hypothesis array, or nullptr = identity (first stage)
-    const int *ns;        // [B,K] how many per (image, keypoint), or nullptr = hn (first stage)
+    const int *lead;      // kCountFilter: [B,K,8] leaders' partial counts [0..3] (-1: none) and their exact counts over the
+                          // pixels the first launch did not count [4..7] (k_lead)
+    int *any_staged;      // one word: kCountFirst writes whether ANY image is staged; k_lead and kCountFilter leave at once
+                          // when none is (a batch of small masks then pays two empty launches, not two table builds)
 };
 
 // chunks with a residue in `mask` among the first n chunks, and the j-th of them (residues present in a last, partial
 // period are a prefix of the sorted residues, so the j-th chunk does not depend on n)
-__device__ __forceinline__ int stage_chunks(uint32_t mask, int M, int n)
+template <uint32_t MASK>
+__device__ __forceinline__ int stage_chunks(int n)
 {
-    return (n / M) * __popc(mask) + __popc(mask & ((1u << (n % M)) - 1u));
+    return (n / kStageM) * __builtin_popcount(MASK) + __popc(MASK & ((1u << (n % kStageM)) - 1u));
 }
-__device__ __forceinline__ int stage_chunk_at(uint32_t mask, int M, int j)
+template <uint32_t MASK>
+__device__ __forceinline__ int stage_chunk_at(int j)
 {
-    const int m = __popc(mask), per = j / m;
-    uint32_t t = mask;
+    constexpr int m = __builtin_popcount(MASK);
+    const int per = j / m;
+    uint32_t t = MASK;
     for (int k = j - per * m; k > 0; --k) t &= t - 1u;
-    return per * M + __builtin_ctz(t);
+    return per * kStageM + __builtin_ctz(t);
+}
+// pixels of an image of tn pixels (nch chunks of PC) that lie in chunks with a residue in MASK
+template <uint32_t MASK>
+__device__ __forceinline__ int stage_pixels(int tn, int nch, int PC)
+{
+    return stage_chunks<MASK>(nch) * PC - (((MASK >> ((nch - 1) % kStageM)) & 1u) ? nch * PC - tn : 0);
 }
 
 // 5 blocks (= 5 waves per SIMD) per CU: <= 96 VGPRs and 30 KB of LDS per block; measured -4.4 % against 4
-template <bool STAGED>
+template <int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_count_bf16(
     const float2 *__restrict__ coords /*[B,cap]*/, const float2 *__restrict__ dirs /*[B,K,cap]*/,
     const float2 *__restrict__ hyps /*[B,K,hn]*/, int *__restrict__ counts /*[B,K,hn]*/,
@@ -142,9 +170,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     __shared__ float4 sP[4 * kBfPixPerWave];        // per pixel: (nhx, nhy, c'x, c'y); nhx = NaN: can never vote  (8 KB)
     __shared__ int sCnt[kBfMaxHt * 32];
     __shared__ float sRed[4];
+    __shared__ unsigned long long s_small[kMaxBatchLds / 64];   // staged: images counted completely by the first launch
+    __shared__ int s_keep[8];                                   // kCountFilter: kept hypotheses per (pass, wave) of a group
+    constexpr bool STAGED = MODE != kCountFull;
+    constexpr bool FILTER = MODE == kCountFilter;
     const int lane = lane_id(), wave = wave_id();
     constexpr int PC = 4 * kBfPixPerWave;
     const int nt = (hn + 31) >> 5;                  // 32-hypothesis tiles per keypoint
+    if constexpr (FILTER) if (*sa.any_staged == 0) return;
 
     // Work item = (image, keypoint, 512-pixel chunk, a run of hypothesis groups).  A group is up to 16 tiles (512
     // hypotheses, what fits the LDS staging); an item walks as many groups as possible (the pixel operands are
@@ -153,10 +186,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     // one, no host sync) and, from the total, the item size.
     if (wave == 0) {
         int carry = 0;
+        [[maybe_unused]] bool any_staged = false;
         for (int b0 = 0; b0 < B; b0 += 64) {
             const int b = b0 + lane;
             int inc = b < B ? (tn_arr[b] + PC - 1) / PC : 0;
-            if constexpr (STAGED) inc = stage_chunks(sa.mask, sa.M, inc);   // this stage's chunks of the image
+            if constexpr (STAGED) {                                // this launch's chunks of the image
+                const bool small = inc < kStageMinChunks;
+                const unsigned long long sm = __ballot(small);
+                any_staged |= sm != ~0ull;
+                if (lane == 0) s_small[b0 >> 6] = sm;
+                inc = small ? (MODE == kCountFirst ? inc : 0) : stage_chunks<MODE == kCountFirst ? kStageFirst : kStageRest>(inc);
+            }
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const int m = __shfl_up(inc, o, 64);
@@ -174,9 +214,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         // groups below 4 tiles only for very small problems (< 128 (chunk, keypoint) pairs: every item they add is another
         // CU put to work); otherwise the prologue of an item is worth more than the 16 matrix-core tiles of a 2-tile group
         const int htpi_min = chunks < 128 ? 2 : 4;
-        if (gpi == 1)
+        if (gpi == 1 && !FILTER)                                    // (the filter compacts groups of 512 hypotheses: no smaller ones)
             while (htpi > htpi_min && chunks * ((nt + htpi - 1) / htpi) < target_items) htpi = (htpi + 1) >> 1;
         if (lane == 0) { s_htpi = htpi; s_gpi = gpi; s_chunks = carry; }
+        if constexpr (MODE == kCountFirst) if (blockIdx.x == 0 && lane == 0) *sa.any_staged = any_staged ? 1 : 0;
     }
     __syncthreads();
     PVV_STAMP(1);
@@ -198,16 +239,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     const int nblk = (total <= target_items + (target_items >> 1) + (target_items >> 2) && (int)gridDim.x > target_items &&
                       (int)gridDim.x <= 3 * target_items) ? target_items : (int)gridDim.x;
     if ((int)blockIdx.x >= nblk) return;
-    for (int item = blockIdx.x; item < total; item += nblk) {
-        const int gchunk = item / per_chunk;                    // chunk index over the whole batch
-        const int rem = item - gchunk * per_chunk;
+    // item -> (chunk over the whole batch, rest) without a division per item: both advance by a constant step
+    const int step_q = nblk / per_chunk, step_r = nblk - step_q * per_chunk;
+    int gchunk = (int)blockIdx.x / per_chunk, rem = (int)blockIdx.x - gchunk * per_chunk;
+    for (int item = blockIdx.x; item < total;
+         item += nblk, gchunk += step_q + (rem + step_r >= per_chunk ? 1 : 0), rem += step_r - (rem + step_r >= per_chunk ? per_chunk : 0)) {
         int local;
         const int b = locate_item(chunk_end, B, gchunk, &local);   // image, and the chunk's index within it (this stage's)
-        const int chunk = STAGED ? stage_chunk_at(sa.mask, sa.M, local) : local;
-        const int vi = rem / nruns;
+        int chunk = local;
+        if constexpr (STAGED)
+            if (!((s_small[b >> 6] >> (b & 63)) & 1ull)) chunk = stage_chunk_at<MODE == kCountFirst ? kStageFirst : kStageRest>(local);
+        const int vi = nruns == 1 ? rem : rem / nruns;          // (one run per (chunk, keypoint) unless the batch is tiny)
         const int run = rem - vi * nruns;
         const int bk = b * K + vi;
-        const float2 *hyp_k = (STAGED ? sa.hyp : hyps) + (size_t)bk * hn;
+        const float2 *hyp_k = hyps + (size_t)bk * hn;
         const float2 *crd = coords + (size_t)b * cap;
         const float2 *dir_k = dirs + (size_t)bk * cap;
         const int pb = chunk * PC;                              // first pixel of the block's chunk (< tn)
@@ -220,8 +265,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         //      per thread (rows beyond tn are read -- the arrays reserve cap rows -- and masked below) and the
         //      hypotheses of the first group.  One memory round trip instead of three.
         const int tn_v = tn_arr[b];
-        int hn_v = hn;                                          // hypotheses alive for this (image, keypoint)
-        if constexpr (STAGED) if (sa.ns) hn_v = sa.ns[bk];
+        int lead_p = -1, lead_r = 0;                            // kCountFilter: a leader's partial count and its exact rest
+        if constexpr (FILTER) {
+            lead_p = sa.lead[(size_t)bk * 8 + (lane & 3)];
+            lead_r = sa.lead[(size_t)bk * 8 + 4 + (lane & 3)];
+        }
         const float2 org = crd[pb];                             // integer origin: the chunk's first pixel
         float2 pc[2], pd[2];
 #pragma unroll
@@ -238,17 +286,58 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             const int h = (g0 * htpi + (i >> 5)) * 32 + (i & 31);
             hp0[q] = (i < nht0 * 32 && h < hn) ? hyp_k[h] : make_float2(0.f, 0.f);
         }
-        const int tn = __builtin_amdgcn_readfirstlane(tn_v);
-        const int hn_k = STAGED ? __builtin_amdgcn_readfirstlane(hn_v) : hn;
-        const int nt_k = STAGED ? (hn_k + 31) >> 5 : nt;          // 32-hypothesis tiles of this (image, keypoint)
-        if constexpr (STAGED) {
-            if (g0 * htpi >= nt_k) continue;                     // block-uniform: this run of groups holds no survivor
+        int cnt0[2] = {0, 0};                                   // kCountFilter: the first launch's counts of those hypotheses
+        if constexpr (FILTER) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {                        // rows beyond the survivors hold stale entries
+            for (int q = 0; q < 2; ++q) {
                 const int i = threadIdx.x + q * kBlock;
-                if ((g0 * htpi + (i >> 5)) * 32 + (i & 31) >= hn_k) hp0[q] = make_float2(0.f, 0.f);
+                const int h = g0 * htpi * 32 + i;
+                if (i < nht0 * 32 && h < hn) cnt0[q] = counts[(size_t)bk * hn + h];
             }
         }
+        const int tn = __builtin_amdgcn_readfirstlane(tn_v);
+        // kCountFilter: R = pixels of the image the first launch did not count; L* = the largest exactly known full count
+        int R_rem = 0, lstar = 0, ns_g = 0;
+        if constexpr (FILTER) {
+            R_rem = stage_pixels<kStageRest>(tn, (tn + PC - 1) / PC, PC);
+            int full = lead_p >= 0 ? lead_p + lead_r : -1;
+            full = max(full, __shfl_xor(full, 1, 64));
+            full = max(full, __shfl_xor(full, 2, 64));
+            lstar = __builtin_amdgcn_readfirstlane(full);
+        }
+        // kCountFilter: stage only the hypotheses of group g that can still reach L*, densely from slot 0 (order = pass,
+        // wave, lane: irrelevant, the counter word carries the hypothesis' index within the group in its high half); pads
+        // the last tile with (0,0) hypotheses.  Contains one barrier; returns the far flag of stage_hypothesis.
+        auto stage_kept = [&](int g, const int (&cnt)[2], const float2 (&hp)[2]) -> int {
+            bool keep[2];
+            unsigned long long m[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = threadIdx.x + q * kBlock;
+                keep[q] = i < htpi * 32 && g * htpi * 32 + i < hn && cnt[q] + R_rem >= lstar;
+                m[q] = __ballot(keep[q]);
+                if (lane == 0) s_keep[q * 4 + wave] = __popcll(m[q]);
+            }
+            __syncthreads();
+            int tot = 0, base[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int v = s_keep[j];
+                tot += v;
+                if (j < wave) base[0] += v;
+                if (j < 4 + wave) base[1] += v;
+            }
+            int f = 0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (keep[q])
+                    f |= stage_hypothesis(sB, sCnt, base[q] + __popcll(m[q] & ((1ull << lane) - 1ull)), hp[q], org,
+                                          (int)(threadIdx.x + q * kBlock) << 16);
+            const int pad = ((tot + 31) & ~31) - tot;
+            if ((int)threadIdx.x < pad) stage_hypothesis(sB, sCnt, tot + threadIdx.x, make_float2(0.f, 0.f), org, 0);
+            ns_g = tot;
+            return f;
+        };
 
         // ---- per pixel (two per thread): the f32 unit normal and the translated coordinates (16 bytes of LDS; the
         //      kappa-scaled perpendicular and the constants -(c-o).nh, -(c-o).B are formed where they are used).  A pixel
@@ -278,11 +367,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         if (lane == 0) sRed[wave] = c1;
         // ---- B operands of the first group (see stage_group below for the layout)
         int far = 0;
-        const int nht0_k = STAGED ? min(nt_k, (g0 + 1) * htpi) - g0 * htpi : nht0;
+        if constexpr (FILTER) {
+            far = stage_kept(g0, cnt0, hp0);
+        } else {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int i = threadIdx.x + q * kBlock;
-            if (i < nht0_k * 32) far |= stage_hypothesis(sB, sCnt, i, hp0[q], org);
+            for (int q = 0; q < 2; ++q) {
+                const int i = threadIdx.x + q * kBlock;
+                if (i < nht0 * 32) far |= stage_hypothesis(sB, sCnt, i, hp0[q], org);
+            }
         }
         far = __syncthreads_or(far);
         PVV_STAMP(4);
@@ -342,25 +434,40 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 
         for (int g = g0; g < g1; ++g) {
             const int ht0 = g * htpi;
-            const int nht = min(nt_k, ht0 + htpi) - ht0;
-            if (STAGED && nht <= 0) break;                       // block-uniform
             if (g > g0) {
                 // ---- B operands of the next group (the first group's were staged with the pixels)
                 far = 0;
-                for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
-                    const int h = (ht0 + (i >> 5)) * 32 + (i & 31);
-                    far |= stage_hypothesis(sB, sCnt, i, h < hn_k ? hyp_k[h] : make_float2(0.f, 0.f), org);
+                if constexpr (FILTER) {
+                    int cnt[2] = {0, 0};
+                    float2 hp[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int i = threadIdx.x + q * kBlock;
+                        const int h = ht0 * 32 + i;
+                        if (i < htpi * 32 && h < hn) { cnt[q] = counts[(size_t)bk * hn + h]; hp[q] = hyp_k[h]; }
+                    }
+                    far = stage_kept(g, cnt, hp);
+                } else {
+                    const int nhtg = min(nt, ht0 + htpi) - ht0;
+                    for (int i = threadIdx.x; i < nhtg * 32; i += kBlock) {
+                        const int h = (ht0 + (i >> 5)) * 32 + (i & 31);
+                        far |= stage_hypothesis(sB, sCnt, i, h < hn ? hyp_k[h] : make_float2(0.f, 0.f), org);
+                    }
                 }
                 far = __syncthreads_or(far);
             }
+            // tiles of this group: its kept hypotheses (filter) or all of them; slot s of the staging holds hypothesis
+            // ht0*32 + s, or -- filter -- ht0*32 + (sCnt[s] >> 16)
+            const int nht = FILTER ? (ns_g + 31) >> 5 : min(nt, ht0 + htpi) - ht0;
+            const int nslot = FILTER ? ns_g : min(hn - ht0 * 32, nht * 32);
             PVV_STAMP(6);
 
             if (__builtin_expect(far, 0)) {
                 // some hypothesis of the group is non-finite / astronomically far: exact loop (K:100-125)
                 for (int ht = 0; ht < nht; ++ht) {
-                    const int h = (ht0 + ht) * 32 + col;
-                    if (h >= hn_k) continue;
-                    const float2 hp = hyp_k[h];
+                    const int slot = ht * 32 + col;
+                    if (slot >= nslot) continue;
+                    const float2 hp = hyp_k[ht0 * 32 + (FILTER ? sCnt[slot] >> 16 : slot)];
                     int inl = 0;
                     for (int p = pb + wave * 2 + kslice; p < min(tn, pb + PC); p += 8) {
                         const float2 c = crd[p], d = dir_k[p];
@@ -414,8 +521,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                     // only then the un-translated hypothesis is fetched (not ahead of the tiles either: that prefetch costs
                     // more issue slots in every iteration than the stall does in a sixth of them, measured +1.6 %)
                     if (__builtin_expect(flagged != 0u, 0) && __any((mb[0] | mb[1]) != 0u)) {
-                        const int h = (ht0 + ht) * 32 + col;
-                        const float2 hp = h < hn_k ? hyp_k[h] : make_float2(0.f, 0.f);
+                        const int slot = ht * 32 + col;
+                        const float2 hp = slot < nslot ? hyp_k[ht0 * 32 + (FILTER ? sCnt[slot] >> 16 : slot)] : make_float2(0.f, 0.f);
                         do {
                             // re-decide the marked evaluations of tile j exactly (K:100-125)
                             const int j = __builtin_ctz(flagged);
@@ -459,14 +566,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             }
             PVV_STAMP(7);
             __syncthreads();
-            for (int i = threadIdx.x; i < nht * 32; i += kBlock) {
-                const int h = ht0 * 32 + i;
-                const int c = sCnt[i];
-                if (h < hn_k && c != 0) {
-                    int dst = h;                                     // survivor row -> index in the hypothesis array
-                    if constexpr (STAGED) if (sa.idx) dst = sa.idx[(size_t)bk * hn + h];
-                    atomicAdd(&counts[(size_t)bk * hn + dst], c);
-                }
+            for (int i = threadIdx.x; i < nslot; i += kBlock) {
+                const int v = sCnt[i];
+                const int c = FILTER ? v & 0xffff : v;               // (filter: index within the group << 16 | count <= 512)
+                if (c != 0) atomicAdd(&counts[(size_t)bk * hn + ht0 * 32 + (FILTER ? v >> 16 : i)], c);
             }
             PVV_STAMP(8);
         }

@@ -1,125 +1,134 @@
-// count_prune.hpp -- stage 3, between two launches of k_count_bf16<true>: exact elimination of hypotheses that can no
-// longer win (ransac_voting_layer_v3 only).
+// count_prune.hpp -- stage 3, between the two launches of the staged count: the leaders' exact full counts
+// (ransac_voting_layer_v3 only).
 // Part of the single translation unit pvnet_vote.hip (included inside its anonymous namespace); see that file
 // for the numerical contract and the reference citations (K = ransac_voting_kernel.cu, P = ransac_voting_gpu.py).
 #pragma once
 
 // ---------------------------------------------------------------------------------------------
 // ransac_voting_layer_v3 keeps, per (image, keypoint), the FIRST hypothesis with the maximal inlier count and that count
-// (torch.max over hn, P:160; ratio update P:162-167); the other hn - 1 counts never leave the layer.  So after the
-// chunks of the stages run so far (a fraction f of the image's pixels, spread over the object) this kernel
-//   1. takes a leader per wavefront (maximal PARTIAL count among the wave's share of the alive hypotheses, first index
-//      among ties -- the four leaders include the overall partial leader) and counts it EXACTLY (K:100-125) over every
-//      pixel not counted yet: four exactly known FULL counts, L* = the largest;
-//   2. keeps hypothesis h alive iff  partial(h) + R >= L*,  R = the number of pixels not counted yet.  A dropped h has
-//      full(h) <= partial(h) + R < L* <= max: it is neither the winner nor tied with it, and what stays in counts[] for
-//      it (its partial count) is below the maximum, so the arg-max kernel (refit.hpp) is unaffected.  Every hypothesis
-//      whose full count equals the maximum survives every stage and ends with its exact count: winner index (first
-//      among ties), winner count and therefore the refit are those of the full pass, bit for bit;
-//   3. writes the survivors -- indices and coordinates, dense, in index order -- for the next stage's launch.
-// One block per (image, keypoint).  With a winner that explains nearly every pixel (LINEMOD-like: ratio ~0.99) a first
-// stage over a quarter of the chunks leaves ~15 % of the hypotheses alive; with 30-50 % outlier pixels (config 4) the
-// bound bites late and little is saved.
+// (torch.max over hn, P:160; ratio update P:162-167); the other hn - 1 counts never leave the layer.  After
+// k_count_bf16<kCountFirst> has counted every hypothesis over a spread quarter of an image's 512-pixel chunks, this kernel
+// takes kLead = 2 leaders per (image, keypoint) -- the best two of the four per-wavefront leaders (maximal PARTIAL count
+// among the wave's share of the hypotheses, first index among ties): the overall partial leader is one of them -- and
+// counts them EXACTLY (K:100-125) over every pixel the first launch did not count.  lead[b,k,0..3] = the leaders' partial
+// counts (-1: none), lead[b,k,4..7] = their counts over the rest: exactly known FULL counts, whose maximum L* bounds the
+// winner's count from below.  The
+// second launch (k_count_bf16<kCountFilter>) then only counts hypotheses with  partial + R >= L*  (count_bf16.hpp).
+//
+// Grid (K * nsplit, B): the remaining pixels of an (image, keypoint) are cut into nsplit shares so that the whole batch is
+// ONE generation of blocks (<= 8 per CU); a thread sees ~10 pixels, all four leaders per pixel, and all its loads are in
+// flight together; the shares add their sums to lead[..4..7] with one atomic each (zeroed by k_compact_hyp).  One block per
+// (image, keypoint) that also compacted the survivors -- the first form of round 3 -- took 36 us at B = 64 (18 dependent
+// memory round trips per block), 4608 short blocks of 2-3 pixels per thread 28 us (two and a half generations of blocks,
+// five round trips each).
 // ---------------------------------------------------------------------------------------------
-struct PruneArgs {
+struct LeadArgs {
     const int *tn_arr;
     const float2 *coords;    // [B,cap]
     const float2 *dirs;      // [B,K,cap]
     const float2 *hyps;      // [B,K,hn]
     const int *counts;       // [B,K,hn] partial counts (of the chunks in done_mask)
-    const int *idx_in;       // [B,K,hn] alive before this prune, or nullptr = all hn
-    const int *ns_in;        // [B,K] or nullptr
-    float2 *hyp_out;         // [B,K,hn]
-    int *idx_out;            // [B,K,hn]
-    int *ns_out;             // [B,K]
+    int *lead;               // [B,K,8]
+    const int *any_staged;   // one word written by k_count_bf16<kCountFirst>: 0 = no image of the batch is staged
     int K, hn, cap;
     float thresh;
-    uint32_t done_mask;      // residues (mod M) of the 512-pixel chunks counted so far
-    int M;
+    int nsplit;
 };
 
-__global__ __launch_bounds__(kBlock) void k_prune(PruneArgs a)
+constexpr int kLead = 2;     // leaders counted exactly per (image, keypoint), <= 4
+
+__global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
 {
-    __shared__ int s_full[4], s_rem[4], s_red[4];
-    const int vi = blockIdx.x, b = blockIdx.y, bk = b * a.K + vi;
+    __shared__ int s_cnt[4], s_idx[4], s_sum[4][4];
+    const int vi = blockIdx.x / a.nsplit, split = blockIdx.x - vi * a.nsplit, b = blockIdx.y, bk = b * a.K + vi;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     constexpr int PC = 4 * kBfPixPerWave;                          // the count kernel's chunk: 512 pixels
+    if (*a.any_staged == 0) return;
     const int tn = a.tn_arr[b];
-    const int n_in = a.ns_in ? a.ns_in[bk] : a.hn;
-    if (tn <= 0 || n_in <= 0) {                                    // image skipped (P:129-132): no stage has items for it
-        if (threadIdx.x == 0) a.ns_out[bk] = 0;
-        return;
-    }
+    const int nch = (tn + PC - 1) / PC;
+    if (tn <= 0 || nch < kStageMinChunks) return;                          // skipped (P:129-132) or counted completely by the first launch
+    // ---- the pixels of the chunks not counted yet, in order: r-th remaining pixel -> chunk stage_chunk_at(rem, r / 512).
+    //      The first trip's loads (kTrip pixels per thread) are issued BEFORE the leader search: they depend on tn alone,
+    //      so the counts, the pixels and then the leaders' hypotheses are three memory round trips, not five.
+    constexpr int kTrip = 10;
+    const int rem_px = stage_pixels<kStageRest>(tn, nch, PC);
+    const int per = (rem_px + a.nsplit - 1) / a.nsplit;
+    const int r1 = min(rem_px, (split + 1) * per);
+    const float2 *crd = a.coords + (size_t)b * a.cap;
+    const float2 *dir = a.dirs + (size_t)bk * a.cap;
+    float2 cc[kTrip], dd[kTrip];
+    auto load_trip = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < kTrip; ++u) {
+            const int r = r0 + u * kBlock;
+            cc[u] = dd[u] = make_float2(0.f, 0.f);                 // zero direction: norm1 < 1e-6, never an inlier
+            if (r < r1) {
+                const int p = stage_chunk_at<kStageRest>(r / PC) * PC + (r & (PC - 1));
+                cc[u] = crd[p];
+                dd[u] = dir[p];
+            }
+        }
+    };
+    int r0 = split * per + threadIdx.x;
+    load_trip(r0);
+    // ---- this wave's leader: maximal partial count, first index among ties
     const int *cp = a.counts + (size_t)bk * a.hn;
-    const int *ip = a.idx_in ? a.idx_in + (size_t)bk * a.hn : nullptr;
-    const float2 *hp = a.hyps + (size_t)bk * a.hn;
-
-    // ---- 1. this wave's leader: maximal partial count, first index among ties
     int best = -1, besth = 0x7fffffff;
-    for (int i = threadIdx.x; i < n_in; i += kBlock) {
-        const int h = ip ? ip[i] : i;
+    for (int h = threadIdx.x; h < a.hn; h += kBlock) {
         const int c = cp[h];
-        if (c > best || (c == best && h < besth)) { best = c; besth = h; }
+        if (c > best) { best = c; besth = h; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const int oc = __shfl_xor(best, o, 64), oh = __shfl_xor(besth, o, 64);
         if (oc > best || (oc == best && oh < besth)) { best = oc; besth = oh; }
     }
-    // ---- its exact count over the pixels no stage has counted yet (K:100-125), four pixels per lane in flight
-    const float2 *crd = a.coords + (size_t)b * a.cap;
-    const float2 *dir = a.dirs + (size_t)bk * a.cap;
-    const float2 lead = best >= 0 ? hp[besth] : make_float2(0.f, 0.f);
-    int inl = 0, rem = 0;
-    const int nch = (tn + PC - 1) / PC;
-    for (int c = 0; c < nch; ++c) {
-        if ((a.done_mask >> (c % a.M)) & 1u) continue;             // wave-uniform
-        const int p0 = c * PC, pe = min(tn, p0 + PC);
-        for (int p = p0 + lane; p < pe; p += 4 * 64) {
-            float2 cc[4], dd[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = p + u * 64;
-                cc[u] = q < pe ? crd[q] : make_float2(0.f, 0.f);
-                dd[u] = q < pe ? dir[q] : make_float2(0.f, 0.f);   // zero direction: norm1 < 1e-6, never an inlier
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                inl += (best >= 0 && vote_exact(cc[u].x, cc[u].y, lead.x, lead.y, dd[u].x, dd[u].y, a.thresh)) ? 1 : 0;
-                rem += p + u * 64 < pe ? 1 : 0;
-            }
-        }
-    }
-    inl = wave_sum(inl);
-    rem = wave_sum(rem);
-    if (lane == 0) { s_full[wave] = best >= 0 ? best + inl : -1; s_rem[wave] = rem; }
+    if (lane == 0) { s_cnt[wave] = best; s_idx[wave] = besth; }
     __syncthreads();
-    const int lstar = max(max(s_full[0], s_full[1]), max(s_full[2], s_full[3]));
-    const int R = s_rem[0];                                        // every wave walked the same pixels
-
-    // ---- 2./3. survivors, in index order
-    const size_t row = (size_t)bk * a.hn;
-    int base = 0;
-    for (int i0 = 0; i0 < n_in; i0 += kBlock) {
-        const int i = i0 + threadIdx.x;
-        int h = 0;
-        bool keep = false;
-        if (i < n_in) {
-            h = ip ? ip[i] : i;
-            keep = cp[h] + R >= lstar;
-        }
-        const unsigned long long m = __ballot(keep);
-        __syncthreads();
-        if (lane == 0) s_red[wave] = __popcll(m);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += s_red[w];
-        off += __popcll(m & ((1ull << lane) - 1ull));
-        if (keep) {
-            a.idx_out[row + off] = h;
-            a.hyp_out[row + off] = hp[h];
-        }
-        base += s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    // the best kLead of the four per-wave leaders (count descending, index ascending): the exact vote costs ~50 VALU
+    // instructions per (pixel, leader) -- four leaders made this kernel VALU-bound at 25 us, and the bound L* is the
+    // overall partial leader's full count in nearly every case
+    int lc[4], li[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { lc[w] = s_cnt[w]; li[w] = s_idx[w]; }
+#pragma unroll
+    for (int i = 0; i < kLead; ++i)
+#pragma unroll
+        for (int j = 3; j > i; --j)
+            if (lc[j] > lc[j - 1] || (lc[j] == lc[j - 1] && li[j] < li[j - 1])) {
+                const int tc = lc[j], ti = li[j];
+                lc[j] = lc[j - 1]; li[j] = li[j - 1]; lc[j - 1] = tc; li[j - 1] = ti;
+            }
+    float2 ld[kLead];
+#pragma unroll
+    for (int w = 0; w < kLead; ++w) ld[w] = lc[w] >= 0 ? a.hyps[(size_t)bk * a.hn + li[w]] : make_float2(0.f, 0.f);
+    if (split == 0 && threadIdx.x < 4) {
+        int v = -1;
+#pragma unroll
+        for (int w = 0; w < kLead; ++w) if ((int)threadIdx.x == w) v = lc[w];
+        a.lead[(size_t)bk * 8 + threadIdx.x] = v;                  // slots kLead..3: no leader
     }
-    if (threadIdx.x == 0) a.ns_out[bk] = base;
+    int inl[kLead];
+#pragma unroll
+    for (int w = 0; w < kLead; ++w) inl[w] = 0;
+    for (;;) {
+#pragma unroll
+        for (int u = 0; u < kTrip; ++u)
+#pragma unroll
+            for (int w = 0; w < kLead; ++w)
+                inl[w] += vote_exact(cc[u].x, cc[u].y, ld[w].x, ld[w].y, dd[u].x, dd[u].y, a.thresh) ? 1 : 0;
+        r0 += kTrip * kBlock;
+        if (r0 - (int)threadIdx.x >= r1) break;                    // block-uniform
+        load_trip(r0);
+    }
+#pragma unroll
+    for (int w = 0; w < kLead; ++w) {
+        const int s = wave_sum(inl[w]);
+        if (lane == 0) s_sum[wave][w] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < kLead) {
+        const int s = s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x] + s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x];
+        if (s) atomicAdd(&a.lead[(size_t)bk * 8 + 4 + threadIdx.x], s);
+    }
 }

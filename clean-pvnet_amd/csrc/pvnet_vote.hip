@@ -73,7 +73,7 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Layout {
     int T;
     size_t tiles, tile_list, tile_draw, tn, surv, coords, dirs, hyps, counts, sums, total;
-    size_t alive_idx[2], alive_hyp[2], alive_n[2];   // staged counting (count_prune.hpp): survivors, ping-pong; 0 = not reserved
+    size_t lead;                                     // staged counting (count_prune.hpp): [B,K,8] leader counts; 0 = not reserved
 };
 
 bool use_bf16_count(const pvv_problem *p);
@@ -96,13 +96,102 @@ Layout make_layout(const pvv_problem *p)
     L.hyps = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
     L.counts = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
     L.sums = take(sizeof(double) * (size_t)p->B * p->K * kRefitSplitMax * 5);
-    for (int i = 0; i < 2; ++i) L.alive_idx[i] = L.alive_hyp[i] = L.alive_n[i] = 0;
-    if (may_stage(p))
-        for (int i = 0; i < 2; ++i) {
-            L.alive_idx[i] = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
-            L.alive_hyp[i] = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
-            L.alive_n[i] = take(sizeof(int) * (size_t)p->B * p->K);
-        }
+    L.lead = may_stage(p) ? take(sizeof(int) * ((size_t)p->B * p->K * 8 + 1)) : 0;   // + the any_staged word
+    L.total = off;
+    return L;
+}
+
+int validate(const pvv_problem *p)
+{
+    if (!p) return fail(PVV_E_ARG, "problem is NULL");
+    if (p->B <= 0 || p->H <= 0 || p->W <= 0 || p->K <= 0 || p->hn <= 0)
+        return fail(PVV_E_ARG, "B, H, W, K, hn must be positive");
+    if (p->B > kMaxBatchLds) return fail(PVV_E_ARG, "B > 1024: split the batch");
+    if (((long long)p->H * p->W + kTile - 1) / kTile > kMaxTiles) return fail(PVV_E_ARG, "H*W too large (more than 16000 tiles of 2048 pixels)");
+    if ((long long)p->K * p->hn >= (1ll << 23)) return fail(PVV_E_ARG, "K*hn must be < 2^23");
+    if (p->count_kernel < PVV_COUNT_AUTO || p->count_kernel > PVV_COUNT_STAGED) return fail(PVV_E_ARG, "unknown count_kernel");
+    if (p->mask_elem_size != 1 && p->mask_elem_size != 2 && p->mask_elem_size != 4 &&
+        p->mask_elem_size != 8)
+        return fail(PVV_E_ARG, "mask_elem_size must be 1, 2, 4 or 8");
+    if (p->cap <= 0 || (long long)p->cap > (long long)p->H * p->W)
+        return fail(PVV_E_ARG, "cap must be in [1, H*W]");
+    if ((long long)p->B * p->K * p->hn >= (1ll << 31) || (long long)p->B * p->K * p->cap >= (1ll << 40))
+        return fail(PVV_E_ARG, "problem too large for one call");
+    if (p->singular_policy < PVV_SINGULAR_REFERENCE || p->singular_policy > PVV_SINGULAR_IMAGE_ZERO)
+        return fail(PVV_E_ARG, "unknown singular_policy");
+    return PVV_OK;
+}
+
+int num_cus()
+{
+    // per device: one process may drive several GPUs (the bench and RCCL use one process per GPU, tests need not)
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        int n = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        cus[dev] = n > 0 ? n : 256;
+    }
+    return cus[dev];
+}
+
+int launch_count(const CountArgs &a, hipStream_t st)
+{
+    const int grid = num_cus() * 8;
+    if (a.hn <= 64)
+        hipLaunchKernelGGL(k_count_inliers<1>, dim3(grid), dim3(kBlock), 0, st, a);
+    else if (a.hn <= 128)
+        hipLaunchKernelGGL(k_count_inliers<2>, dim3(grid), dim3(kBlock), 0, st, a);
+    else if (a.hn <= 256)
+        hipLaunchKernelGGL(k_count_inliers<4>, dim3(grid), dim3(kBlock), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_count_inliers<8>, dim3(grid), dim3(kBlock), 0, st, a);
+    return check_launch("k_count_inliers");
+}
+
+// The matrix-core prefilter needs 0 < T < 1 with a sane kappa and pixel coordinates well inside the range where the
+// block extents of its guard band are exact; outside [0.5, 0.99995], for huge images, and when the caller asks for it
+// (pvv_problem.count_kernel = PVV_COUNT_EXACT: the tests' cross-check) the exact kernel counts.
+bool use_bf16_count(const pvv_problem *p)
+{
+    return p->count_kernel != PVV_COUNT_EXACT && p->inlier_thresh >= 0.5f && p->inlier_thresh <= 0.99995f &&
+           p->H <= 16384 && p->W <= 16384;
+}
+
+// Staged counting with exact elimination (count_bf16.hpp / count_prune.hpp) is something only ransac_voting_layer_v3
+// can use (it keeps the arg-max; the estimate weighs every hypothesis).  may_stage: the workspace reserves the leader
+// words (a property of the problem alone, so that pvv_workspace_bytes needs no extra argument); a v3 call whose problem
+// may stage takes the staged path.  PVV_COUNT_STAGED forces it wherever the matrix-core kernel is valid, PVV_COUNT_FULL
+// forbids it, AUTO stages when the batch is large enough for the two extra launches (k_lead + the second count launch)
+// to pay.  The host knows neither tn nor the winners' inlier ratios, so the rule is a proxy for the evaluations of a full
+// pass, B*K*hn*H*W >= 3e10 -- measured on MI355X (tools/staged_ab.py): 480x640, K = 9, 512 hypotheses breaks even at
+// B = 16 (2.3e10), +4 % at B = 32, +24 % at B = 64; 540x720, K = 17, 2048 hypotheses at B = 16 (2.2e11) +86 % -- and the
+// DEVICE refines it per image: images of fewer than 8 chunks (tn <= 3584) are counted completely by the first launch, and
+// when no image of the batch is staged the two later launches leave at their first instruction (config 4's sparse masks
+// at B = 32: the call then costs ~5 us more than the full pass, the price of not knowing tn on the host).
+constexpr double kStageMinWork = 3e10;
+bool may_stage(const pvv_problem *p);
+
+Layout make_layout(const pvv_problem *p)
+{
+    Layout L;
+    const size_t HW = (size_t)p->H * p->W;
+    L.T = (int)((HW + kTile - 1) / kTile);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+    L.tiles = take(sizeof(uint32_t) * (size_t)p->B * L.T);
+    L.tile_list = take(sizeof(unsigned short) * (size_t)p->B * L.T * kTile);
+    L.tile_draw = take(sizeof(float) * (size_t)p->B * L.T * kTile);
+    L.tn = take(sizeof(int) * (size_t)p->B);
+    L.surv = take(sizeof(int) * (size_t)p->B * kSurvCap);
+    L.coords = take(sizeof(float2) * (size_t)p->B * p->cap);
+    L.dirs = take(sizeof(float2) * (size_t)p->B * p->K * p->cap);
+    L.hyps = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
+    L.counts = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
+    L.sums = take(sizeof(double) * (size_t)p->B * p->K * kRefitSplitMax * 5);
+    L.lead = may_stage(p) ? take(sizeof(int) * ((size_t)p->B * p->K * 8 + 1)) : 0;   // + the any_staged word
     L.total = off;
     return L;
 }
@@ -172,12 +261,12 @@ bool use_bf16_count(const pvv_problem *p)
 // takes the staged path.  PVV_COUNT_STAGED forces it wherever the matrix-core kernel is valid, PVV_COUNT_FULL forbids
 // it, AUTO stages when the batch is large enough for the two extra launches (k_prune + the second count launch,
 // ~8 us) to pay: measured on MI355X at 480x640 / 512 hypotheses -- see DESIGN.md 4.6.
-constexpr long long kStageMinPixels = 12ll * 480 * 640;
+constexpr long long kStageMinPixels = 24ll * 480 * 640;
 bool may_stage(const pvv_problem *p)
 {
     if (!use_bf16_count(p) || p->count_kernel == PVV_COUNT_FULL) return false;
     if (p->count_kernel == PVV_COUNT_STAGED) return true;
-    return p->hn >= 128 && (long long)p->B * p->H * p->W >= kStageMinPixels;
+    return p->hn >= 128 && (double)p->B * p->K * p->hn * p->H * p->W >= kStageMinWork;
 }
 
 Bf16Consts bf16_consts(float thresh)
@@ -207,7 +296,13 @@ Bf16Consts bf16_consts(float thresh)
 int tuning_int(const char *name, int dflt)
 {
 #ifdef PVV_TUNING
+    // read ONCE per knob (tools/variant_ab.py loads a copy of the library per setting and restores the environment after
+    // its first launches)
+    static const char *names[32];
+    static int vals[32], n = 0;
+    for (int i = 0; i < n; ++i) if (!strcmp(names[i], name)) return vals[i] == INT32_MIN ? dflt : vals[i];
     const char *e = getenv(name);
+    if (n < 32) { names[n] = name; vals[n] = e && *e ? atoi(e) : INT32_MIN; ++n; }
     return e && *e ? atoi(e) : dflt;
 #else
     (void)name;
@@ -232,25 +327,6 @@ int mark(const pvv_problem *p, int i, hipStream_t st)
     if (!p->ev_marks || !p->ev_marks[i]) return PVV_OK;
     if (hipEventRecord((hipEvent_t)p->ev_marks[i], st) != hipSuccess) return fail(PVV_E_ARG, "ev_marks holds an invalid hipEvent_t");
     return PVV_OK;
-}
-
-// The chunk schedule of the staged count: stage s counts the 512-pixel chunks c with (c mod M) in mask[s].  Two stages:
-// a quarter of the chunks, spread over the object (rows of the compacted list = raster order), then -- for the
-// hypotheses k_prune left alive -- the rest.
-struct StageSchedule { int n, M; uint32_t mask[4]; };
-StageSchedule stage_schedule()
-{
-    StageSchedule sc;
-    sc.n = tuning_int("PVV_STAGES", 2);
-    sc.M = tuning_int("PVV_STAGE_M", 8);
-    const uint32_t all = (1u << sc.M) - 1u;
-    sc.mask[0] = (uint32_t)tuning_int("PVV_STAGE_MASK0", 0x22) & all;          // residues 1 and 5 of 8
-    sc.mask[1] = (uint32_t)tuning_int("PVV_STAGE_MASK1", sc.n > 2 ? 0x88 : 0) & all;
-    sc.mask[2] = (uint32_t)tuning_int("PVV_STAGE_MASK2", 0) & all;
-    uint32_t used = 0;
-    for (int i = 0; i < sc.n - 1; ++i) { sc.mask[i] &= ~used; used |= sc.mask[i]; }
-    sc.mask[sc.n - 1] = all & ~used;                                            // the last stage: everything left
-    return sc;
 }
 
 int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, bool staged)
@@ -280,44 +356,40 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     const int *tn = (const int *)(ws + L.tn);
     const Bf16Consts fc = bf16_consts(p->inlier_thresh);
     const int target = tuning_int("PVV_TARGET_ITEMS", items_per_cu * num_cus());
+    const int target_first = tuning_int("PVV_TARGET_ITEMS_FIRST", target), target_filter = tuning_int("PVV_TARGET_ITEMS_FILTER", target);
+    const int per_cu_first = tuning_int("PVV_GRID_PER_CU_FIRST", per_cu), per_cu_filter = tuning_int("PVV_GRID_PER_CU_FILTER", per_cu);
     long long *dbg = tuning_ptr("PVV_DBG_PTR");
     if (!staged) {
-        hipLaunchKernelGGL(k_count_bf16<false>, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
-                           p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target, dbg, StageArgs{0u, 1, nullptr, nullptr, nullptr});
+        hipLaunchKernelGGL(k_count_bf16<kCountFull>, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
+                           p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target, dbg, StageArgs{nullptr, nullptr});
         return check_launch("k_count_bf16");
     }
-    // ransac_voting_layer_v3, staged: count a spread quarter of the chunks for every hypothesis, drop the hypotheses that
-    // can no longer reach a leader's exactly known full count, count the rest for the survivors (count_prune.hpp)
-    const StageSchedule sc = stage_schedule();
-    uint32_t done = 0;
-    for (int s = 0; s < sc.n; ++s) {
-        StageArgs sa;
-        sa.mask = sc.mask[s];
-        sa.M = sc.M;
-        const int in = (s - 1) & 1, out = s & 1;
-        sa.hyp = s == 0 ? hyps : (const float2 *)(ws + L.alive_hyp[in]);
-        sa.idx = s == 0 ? nullptr : (const int *)(ws + L.alive_idx[in]);
-        sa.ns = s == 0 ? nullptr : (const int *)(ws + L.alive_n[in]);
-        if (sa.mask) {
-            hipLaunchKernelGGL(k_count_bf16<true>, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
-                               p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target, dbg, sa);
-            if (int e = check_launch("k_count_bf16<staged>")) return e;
-        }
-        done |= sa.mask;
-        if (s == 0) if (int e = mark(p, PVV_MARK_STAGE0, st)) return e;
-        if (s == sc.n - 1) break;
-        PruneArgs pa;
-        pa.tn_arr = tn; pa.coords = coords; pa.dirs = dirs; pa.hyps = hyps; pa.counts = counts;
-        pa.idx_in = sa.idx; pa.ns_in = sa.ns;
-        pa.hyp_out = (float2 *)(ws + L.alive_hyp[out]); pa.idx_out = (int *)(ws + L.alive_idx[out]);
-        pa.ns_out = (int *)(ws + L.alive_n[out]);
-        pa.K = p->K; pa.hn = p->hn; pa.cap = p->cap; pa.thresh = p->inlier_thresh;
-        pa.done_mask = done; pa.M = sc.M;
-        hipLaunchKernelGGL(k_prune, dim3(p->K, p->B), dim3(kBlock), 0, st, pa);
-        if (int e = check_launch("k_prune")) return e;
-        if (s == 0) if (int e = mark(p, PVV_MARK_PRUNE0, st)) return e;
-    }
-    return PVV_OK;
+    // ransac_voting_layer_v3, staged: count a spread quarter of the chunks for every hypothesis, count four leaders
+    // exactly over the rest (k_lead), then the rest only for the hypotheses that can still reach the best leader
+    int *lead = (int *)(ws + L.lead);
+    StageArgs sa;
+    sa.lead = nullptr;
+    sa.any_staged = lead + (size_t)p->B * p->K * 8;
+    hipLaunchKernelGGL(k_count_bf16<kCountFirst>, dim3(per_cu_first * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
+                       p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target_first, dbg, sa);
+    if (int e = check_launch("k_count_bf16<first>")) return e;
+    if (int e = mark(p, PVV_MARK_STAGE0, st)) return e;
+    LeadArgs la;
+    la.tn_arr = tn; la.coords = coords; la.dirs = dirs; la.hyps = hyps; la.counts = counts; la.lead = lead;
+    la.K = p->K; la.hn = p->hn; la.cap = p->cap; la.thresh = p->inlier_thresh;
+    la.any_staged = sa.any_staged;
+    // shares per (image, keypoint): the largest power of two <= 16 that keeps the grid within one generation of blocks
+    // (8 per CU)
+    la.nsplit = 16;
+    while (la.nsplit > 1 && (long long)p->B * p->K * la.nsplit > 8ll * num_cus()) la.nsplit >>= 1;
+    la.nsplit = tuning_int("PVV_LEAD_SPLIT", la.nsplit);
+    hipLaunchKernelGGL(k_lead, dim3(p->K * la.nsplit, p->B), dim3(kBlock), 0, st, la);
+    if (int e = check_launch("k_lead")) return e;
+    if (int e = mark(p, PVV_MARK_PRUNE0, st)) return e;
+    sa.lead = lead;
+    hipLaunchKernelGGL(k_count_bf16<kCountFilter>, dim3(per_cu_filter * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
+                       p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target_filter, dbg, sa);
+    return check_launch("k_count_bf16<filter>");
 }
 
 CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
@@ -342,7 +414,7 @@ int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_
 {
     if (p->ev_count_begin && hipEventRecord((hipEvent_t)p->ev_count_begin, st) != hipSuccess)
         return fail(PVV_E_ARG, "ev_count_begin is not a valid hipEvent_t");
-    const bool staged = v3 && may_stage(p) && L.alive_n[0] != 0;
+    const bool staged = v3 && may_stage(p) && L.lead != 0;
     const int e = use_bf16_count(p) ? launch_count_bf16(p, L, ws, st, staged) : launch_count(planar_count_args(p, L, ws), st);
     if (e) return e;
     if (p->ev_count_end && hipEventRecord((hipEvent_t)p->ev_count_end, st) != hipSuccess)
@@ -434,6 +506,7 @@ Front make_front(const pvv_problem *p, int mode, const void *d_mask, const float
     h.draws_out = p->d_draws_out;
     h.blocks = (int)(((long long)p->K * p->hn + kBlock - 1) / kBlock);
     h.surv = (int *)(ws + L.surv);
+    h.lead = L.lead ? (int *)(ws + L.lead) : nullptr;
     return f;
 }
 
@@ -647,6 +720,7 @@ PVV_EXPORT int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace, s
     char *ws = (char *)d_workspace;
     if (zero_counts) {
         hipError_t e = hipMemsetAsync(ws + L.counts, 0, sizeof(int) * (size_t)p->B * p->K * p->hn, st);
+        if (e == hipSuccess && L.lead) e = hipMemsetAsync(ws + L.lead, 0, sizeof(int) * ((size_t)p->B * p->K * 8 + 1), st);
         if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     }
     return launch_count_any(p, L, ws, st, v3);

@@ -1,6 +1,6 @@
 """GPU parity of the round-3 additions to the count pass (ABI v6):
 
-  * staged counting with exact elimination (k_count_bf16<true> + k_prune, ransac_voting_layer_v3 only) against the full
+  * staged counting with exact elimination (k_count_bf16<first> + k_lead + k_count_bf16<filter>, ransac_voting_layer_v3 only) against the full
     pass, against the reference's own arithmetic (PVV_COUNT_EXACT) and against the oracle -- winners, winner counts and
     means bit for bit / within the one tolerance, on the randomized soak cases and at the BASELINE configs' OWN batch
     sizes, where the count kernel's scheduling branches flip (VERDICT r2 #2a: cfg3 at B = 8/16/24/32, cfg4 at B = 32,
@@ -126,8 +126,7 @@ def test_estimate_with_4096_hypotheses_at_batch_sizes(oracle, synth, pkg, gpu, B
 
 def test_staged_count_with_ties_empty_images_and_few_chunks(oracle, synth, pkg, gpu):
     """Corner cases of the elimination: an image without foreground and one below min_num beside normal ones, an image of
-    a single 512-pixel chunk (its chunk belongs to the LAST stage: the first stage counts nothing, k_prune keeps every
-    hypothesis), duplicated index pairs (tied hypotheses: the FIRST index must win, P:160) and a keypoint nobody votes for
+    a single 512-pixel chunk (fewer than n_min chunks: counted completely by the first launch), duplicated index pairs (tied hypotheses: the FIRST index must win, P:160) and a keypoint nobody votes for
     (all counts 0: winner stays (0,0), P:162-167)."""
     from clean_pvnet_amd import ransac_voting as ext
     c = {**synth.CONFIGS["cfg2"], "B": 5, "H": 240, "W": 320, "fg": 0.1}
@@ -202,7 +201,7 @@ def test_stage_marks_and_stream_probe(synth, pkg, gpu):
         for r in ms[2:]:
             assert all(0 < x < 5 for x in r[:5]), r              # scan, compact, count pass, select, finalize: ms
             if staged:
-                assert 0 < r[5] < r[2] and 0 < r[6] < r[2], r    # first count launch and first prune inside the count pass
+                assert 0 < r[5] < r[2] and 0 < r[6] < r[2], r    # first count launch and k_lead inside the count pass
             else:
                 assert r[5] < 0 and r[6] < 0, r                  # not recorded
     buf = torch.empty(256 << 20, dtype=torch.uint8, device=gpu).random_(0, 255)
