@@ -172,96 +172,6 @@ bool use_bf16_count(const pvv_problem *p)
 // when no image of the batch is staged the two later launches leave at their first instruction (config 4's sparse masks
 // at B = 32: the call then costs ~5 us more than the full pass, the price of not knowing tn on the host).
 constexpr double kStageMinWork = 3e10;
-bool may_stage(const pvv_problem *p);
-
-Layout make_layout(const pvv_problem *p)
-{
-    Layout L;
-    const size_t HW = (size_t)p->H * p->W;
-    L.T = (int)((HW + kTile - 1) / kTile);
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
-    L.tiles = take(sizeof(uint32_t) * (size_t)p->B * L.T);
-    L.tile_list = take(sizeof(unsigned short) * (size_t)p->B * L.T * kTile);
-    L.tile_draw = take(sizeof(float) * (size_t)p->B * L.T * kTile);
-    L.tn = take(sizeof(int) * (size_t)p->B);
-    L.surv = take(sizeof(int) * (size_t)p->B * kSurvCap);
-    L.coords = take(sizeof(float2) * (size_t)p->B * p->cap);
-    L.dirs = take(sizeof(float2) * (size_t)p->B * p->K * p->cap);
-    L.hyps = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
-    L.counts = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
-    L.sums = take(sizeof(double) * (size_t)p->B * p->K * kRefitSplitMax * 5);
-    L.lead = may_stage(p) ? take(sizeof(int) * ((size_t)p->B * p->K * 8 + 1)) : 0;   // + the any_staged word
-    L.total = off;
-    return L;
-}
-
-int validate(const pvv_problem *p)
-{
-    if (!p) return fail(PVV_E_ARG, "problem is NULL");
-    if (p->B <= 0 || p->H <= 0 || p->W <= 0 || p->K <= 0 || p->hn <= 0)
-        return fail(PVV_E_ARG, "B, H, W, K, hn must be positive");
-    if (p->B > kMaxBatchLds) return fail(PVV_E_ARG, "B > 1024: split the batch");
-    if (((long long)p->H * p->W + kTile - 1) / kTile > kMaxTiles) return fail(PVV_E_ARG, "H*W too large (more than 16000 tiles of 2048 pixels)");
-    if ((long long)p->K * p->hn >= (1ll << 23)) return fail(PVV_E_ARG, "K*hn must be < 2^23");
-    if (p->count_kernel < PVV_COUNT_AUTO || p->count_kernel > PVV_COUNT_STAGED) return fail(PVV_E_ARG, "unknown count_kernel");
-    if (p->mask_elem_size != 1 && p->mask_elem_size != 2 && p->mask_elem_size != 4 &&
-        p->mask_elem_size != 8)
-        return fail(PVV_E_ARG, "mask_elem_size must be 1, 2, 4 or 8");
-    if (p->cap <= 0 || (long long)p->cap > (long long)p->H * p->W)
-        return fail(PVV_E_ARG, "cap must be in [1, H*W]");
-    if ((long long)p->B * p->K * p->hn >= (1ll << 31) || (long long)p->B * p->K * p->cap >= (1ll << 40))
-        return fail(PVV_E_ARG, "problem too large for one call");
-    if (p->singular_policy < PVV_SINGULAR_REFERENCE || p->singular_policy > PVV_SINGULAR_IMAGE_ZERO)
-        return fail(PVV_E_ARG, "unknown singular_policy");
-    return PVV_OK;
-}
-
-int num_cus()
-{
-    // per device: one process may drive several GPUs (the bench and RCCL use one process per GPU, tests need not)
-    static int cus[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (!cus[dev]) {
-        hipDeviceProp_t prop;
-        int n = 0;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        cus[dev] = n > 0 ? n : 256;
-    }
-    return cus[dev];
-}
-
-int launch_count(const CountArgs &a, hipStream_t st)
-{
-    const int grid = num_cus() * 8;
-    if (a.hn <= 64)
-        hipLaunchKernelGGL(k_count_inliers<1>, dim3(grid), dim3(kBlock), 0, st, a);
-    else if (a.hn <= 128)
-        hipLaunchKernelGGL(k_count_inliers<2>, dim3(grid), dim3(kBlock), 0, st, a);
-    else if (a.hn <= 256)
-        hipLaunchKernelGGL(k_count_inliers<4>, dim3(grid), dim3(kBlock), 0, st, a);
-    else
-        hipLaunchKernelGGL(k_count_inliers<8>, dim3(grid), dim3(kBlock), 0, st, a);
-    return check_launch("k_count_inliers");
-}
-
-// The matrix-core prefilter needs 0 < T < 1 with a sane kappa and pixel coordinates well inside the range where the
-// block extents of its guard band are exact; outside [0.5, 0.99995], for huge images, and when the caller asks for it
-// (pvv_problem.count_kernel = PVV_COUNT_EXACT: the tests' cross-check) the exact kernel counts.
-bool use_bf16_count(const pvv_problem *p)
-{
-    return p->count_kernel != PVV_COUNT_EXACT && p->inlier_thresh >= 0.5f && p->inlier_thresh <= 0.99995f &&
-           p->H <= 16384 && p->W <= 16384;
-}
-
-// Staged counting with exact elimination (count_bf16.hpp / count_prune.hpp) is something only ransac_voting_layer_v3
-// can use (it keeps the arg-max; the estimate weighs every hypothesis).  may_stage: the workspace reserves the survivor
-// lists (a property of the problem alone, so that pvv_workspace_bytes needs no extra argument); stage_v3: this v3 call
-// takes the staged path.  PVV_COUNT_STAGED forces it wherever the matrix-core kernel is valid, PVV_COUNT_FULL forbids
-// it, AUTO stages when the batch is large enough for the two extra launches (k_prune + the second count launch,
-// ~8 us) to pay: measured on MI355X at 480x640 / 512 hypotheses -- see DESIGN.md 4.6.
-constexpr long long kStageMinPixels = 24ll * 480 * 640;
 bool may_stage(const pvv_problem *p)
 {
     if (!use_bf16_count(p) || p->count_kernel == PVV_COUNT_FULL) return false;
