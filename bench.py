@@ -2,30 +2,39 @@
 """bench.py -- images/s of the RANSAC-voting hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+    (N > 1: the driver launches it under torch.distributed.run, one rank per GPU, RCCL; launched BARE with --gpus N > 1 it
+     starts its N ranks itself the same way)
 
 A *step* is one ``ransac_voting_layer_v3(mask, vertex, 512, inlier_thresh=0.99)`` call through the drop-in Python API
 on a device-resident synthetic batch (free-running device RNG, exactly the call of resnet18.py:71), followed -- whenever
 a process group exists -- by the RCCL all_gather of the ``[B,K,2]`` keypoints, waited for INSIDE the step it belongs to.
 
-Workload = BASELINE config 3: 480x640, K=9, 512 hypotheses, ~2 % foreground, GLOBAL batch 64.
-  N = 1   the whole batch on one GPU (the configuration the roofline target is quoted on);
-  N > 1   STRONG scaling, as config 3 says ("batch=64 sharded over 8xMI355X"): the same 64 images, 64/N per GPU,
-          contiguous shards (clean_pvnet_amd.dist.shard_bounds), every image generated from its global index.
-          The weak-scaling figure (64 images PER GPU) and the variant that overlaps the exchange of step i with the
-          voting of step i+1 are reported in ``extra`` (--no-weak skips them).
+Workload = BASELINE config 3: 480x640, K=9, 512 hypotheses, ~2 % foreground, 64 images.
+  N = 1   the 64 images on one GPU (the configuration the roofline target is quoted on);
+  N > 1   WEAK scaling (default, ``"scaling": "weak"``): 64 images PER GPU, global batch 64 N -- every rank decodes the
+          batch its own network produced and the ranks exchange the keypoints: images are independent units, the path
+          shards with no data-path collective.  ``--scaling strong`` is BASELINE config 3 read literally ("batch=64
+          sharded over 8xMI355X"): the same 64 images in contiguous shards of 64/N (clean_pvnet_amd.dist.shard_bounds).
+          Whichever is not the headline is measured in the same run and reported in ``extra`` (with the variant that
+          overlaps the exchange of step i with the voting of step i+1); every image is generated from its global index.
 Steps cycle over --rotate (default 3) distinct device-resident batches, so that neither the 256 MiB Infinity Cache nor
 the L2 holds a step's inputs from the step before.
 
 One JSON line on rank 0.  Besides the contract fields it carries
-  step_ms       per-step HIP events on the launch stream: median / p10 / p90 (the contract's ``ms_per_step`` is the wall
-                clock over the K steps, barrier + synchronize on both sides, max over ranks)
-  roofline      the inlier-count kernel (dominant): dense-field algorithmic bytes / its duration, measured here with HIP
-                events around re-launches of that kernel alone; ``traffic`` from the committed PMC file (static)
-  roofline_valu the same kernel against what actually bounds it: fp32 VALU issue
-  cpu_baseline  the oracle (oracle/vote_oracle.c, OpenMP) on the host cores for a bounded sample of the same images,
-                rank 0, N = 1 only
-  extra         per-phase numbers; with --extras also B=1 latency (config 2), v3 + estimate, the default path, decode
+  step_ms          per-step HIP events on the launch stream: median / p10 / p90 (the contract's ``ms_per_step`` is the wall
+                   clock over the K steps, barrier + synchronize on both sides, max over ranks)
+  roofline         the inlier-count PASS (dominant: k_count_bf16, or -- staged -- its two launches + k_lead): SURVEY 8d's
+                   dense-field bytes / its average duration, from HIP events the library records at the stage boundaries
+                   INSIDE full calls (pvv_problem.ev_marks); ``traffic`` from the committed PMC file (static)
+  roofline_call    the same bytes / ms_per_step: the whole call against the dense field
+  roofline_scan, roofline_compact   the two HBM-facing kernels against what they move, and against the box's own
+                   streaming-read rate (pvv_stream_read_probe, measured in this run)
+  roofline_valu    the count pass against fp32 VALU issue, in equivalent evaluations of a full pass
+  cpu_baseline     the oracle (oracle/vote_oracle.c) on the host: one thread and OpenMP over the cores, a bounded sample of
+                   the timed images -- and the SAME images with the SAME index pairs through the GPU path, cross-checked
+                   (winner counts equal, means within the contract); rank 0, N = 1 only
+  extra            per-kernel durations inside calls, rank / shard bookkeeping; with --extras also B=1 latency (config 2),
+                   v3 + estimate, the default path, decode
 """
 import argparse
 import json
@@ -82,7 +91,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-stream", action="store_true",
                     help="N = 1: skip the two-stream extra (profiling runs: overlapped launches would blur per-kernel durations)")
-    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the weak-scaling and overlapped variants")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak (default) = --batch images PER GPU, global batch N x --batch (each rank decodes the batch its own "
+                         "network produced: the deployment, and what the tier's rule for a path that shards prescribes); strong = "
+                         "the SAME --batch images cut into N contiguous shards (BASELINE config 3 read literally); the other "
+                         "mode is measured too and reported in `extra`")
+    ap.add_argument("--no-weak", "--no-other-scaling", dest="no_other", action="store_true",
+                    help="N > 1: skip the other scaling mode and the overlapped-exchange variant")
     ap.add_argument("--extras", action="store_true",
                     help="also time config 2 (B=1 latency) and v3+estimate; off by default so that a rocprofv3 "
                          "--stats run of the default command sees the count kernel at ONE problem size")
@@ -130,7 +145,8 @@ def main():
     H, W, K, hn = cfg["H"], cfg["W"], cfg["K"], cfg["hn"]
     thresh = 0.99
     gen_cfg = {k: v for k, v in cfg.items() if k not in ("B", "hn")}
-    global_batch = args.batch
+    weak = args.scaling == "weak"
+    global_batch = args.batch * world if weak else args.batch          # weak: --batch images per GPU; strong: in total
     lo, hi = pdist.shard_bounds(global_batch, world, rank)            # this rank's contiguous shard
     B = hi - lo
     # --rotate distinct batches (excluded from timing); batch r holds the global images r*global_batch + [lo, hi)
@@ -224,16 +240,18 @@ def main():
         ring.join()
         two_stream = {"two_stream_images_per_s": round(global_batch * n2 / ts_el, 1), "two_stream_ms_per_step": round(1e3 * ts_el / n2, 4)}
 
-    # N > 1 extras: weak scaling (global_batch images PER GPU) and the exchange overlapped with the next step's voting
-    weak = None
-    if use_dist and world > 1 and not args.no_weak:
-        wb = [synth.make_batch(B=global_batch, **gen_cfg, first_index=(100 + r) * global_batch * world + rank * global_batch,
-                               device=dev) for r in range(2)]
-        def weak_step(i):
-            d = wb[i % 2]
-            local = ransac_voting_layer_v3(d["mask"], d["vertex"], hn, inlier_thresh=thresh)
-            return pdist.gather_results(local, global_batch * world)
-        w_el, w_per, _ = run(weak_step, 5, max(10, args.steps // 4))
+    # N > 1 extras: the OTHER scaling mode (strong when the headline is weak and vice versa) and the exchange overlapped with
+    # the next step's voting
+    other = None
+    if use_dist and world > 1 and not args.no_other:
+        o_global = args.batch if weak else args.batch * world          # the other mode's global batch
+        olo, ohi = pdist.shard_bounds(o_global, world, rank)
+        ob = [synth.make_batch(B=ohi - olo, **gen_cfg, first_index=(100 + r) * o_global + olo, device=dev) if ohi > olo else None
+              for r in range(2)]
+        def other_step(i):
+            return pdist.gather_results(vote(ob[i % 2]), o_global)
+        n2 = max(10, args.steps // 4)
+        w_el, w_per, _ = run(other_step, 5, n2)
         pending = []
         def overlapped_step(i):
             local = vote(batches[i % len(batches)])
@@ -242,13 +260,15 @@ def main():
             ow = pdist.gather_results(local, global_batch, async_op=True)
             pending.append(ow)
             return ow[0]
-        o_el, o_per, _ = run(overlapped_step, 5, max(10, args.steps // 4))
+        o_el, o_per, _ = run(overlapped_step, 5, n2)
         while pending:
             pending.pop()[1].wait()
-        n2 = max(10, args.steps // 4)
-        weak = {"weak_scaling_images_per_s": round(global_batch * world * n2 / w_el, 1),
-                "weak_scaling_ms_per_step": round(1e3 * w_el / n2, 4), "weak_batch_per_gpu": global_batch,
-                "strong_overlapped_exchange_images_per_s": round(global_batch * n2 / o_el, 1)}
+        oname = "strong" if weak else "weak"
+        other = {"%s_scaling_images_per_s" % oname: round(o_global * n2 / w_el, 1),
+                 "%s_scaling_ms_per_step" % oname: round(1e3 * w_el / n2, 4),
+                 "%s_scaling_global_batch" % oname: o_global, "%s_scaling_images_per_gpu" % oname: ohi - olo,
+                 "overlapped_exchange_images_per_s": round(global_batch * n2 / o_el, 1)}
+        del ob
 
     # Durations of the kernels AS THEY RUN INSIDE FULL CALLS: HIP events recorded by the library at the stage boundaries of
     # `reps` calls on the launch stream (pvv_problem.ev_marks), cycling over the rotating batches exactly as the timed steps
@@ -406,9 +426,9 @@ def main():
                  "kernels_inside_calls_ms": stage, "stream_read_probe": probe, "count_pass_staged": staged_path,
                  "exchange": ("all_gather_into_tensor of [%d,%d,2] f32 inside every step" % (global_batch, K)) if use_dist else None}
         if world > 1:
-            extra["scaling_vs_n1_profile"] = predict_from_profile(args.config, global_batch, world, max(shard_sizes), value)
-        if weak:
-            extra.update(weak)
+            extra["scaling_vs_n1_profile"] = predict_from_profile(args.config, global_batch, world, max(shard_sizes), value, weak)
+        if other:
+            extra.update(other)
         if two_stream:
             extra.update(two_stream)
         if world == 1 and args.extras:
@@ -424,15 +444,17 @@ def main():
         result = {
             "metric": "images/sec RANSAC-vote (480x640, K=9, 512 hyp)", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 3 (%s): %dx%d, K=%d, %d hypotheses, ~%.0f%% foreground, int64 mask, contiguous "
-                                   "[B,H,W,K,2] f32 vertex; GLOBAL batch %d in contiguous shards of %d images per GPU; "
+                                   "[B,H,W,K,2] f32 vertex; global batch %d in contiguous shards of %d images per GPU; "
                                    "ransac_voting_layer_v3 (+ RCCL all_gather of [B,K,2] inside the step for N>1); steps "
                                    "cycle over %d distinct device-resident batches"
                                    % (args.config, H, W, K, hn, 100 * (cfg["fg"] if not isinstance(cfg["fg"], tuple) else cfg["fg"][1]),
                                       global_batch, B, len(batches)),
                        "batch_per_gpu": B, "global_batch": global_batch, "H": H, "W": W, "K": K, "hn": hn,
-                       "inlier_thresh": thresh, "parallelism": "batch-sharded x%d (strong scaling)" % world},
+                       "inlier_thresh": thresh,
+                       "parallelism": ("x%d GPUs, %d images per GPU (weak scaling: global batch %d)" % (world, B, global_batch)) if weak
+                                      else ("batch-sharded x%d (strong scaling: %d images in total)" % (world, global_batch))},
             "step_ms": {"median": round(pct(per_step, 0.5), 4), "p10": round(pct(per_step, 0.1), 4),
                         "p90": round(pct(per_step, 0.9), 4), "wall": round(ms_per_step, 4),
                         "how": "torch.cuda.Event pairs around every step on the launch stream (rank 0); wall = perf_counter over the timed region / steps, max over ranks"},
@@ -446,10 +468,11 @@ def main():
     return result
 
 
-def predict_from_profile(config, global_batch, world, shard, value):
+def predict_from_profile(config, global_batch, world, shard, value, weak):
     """What the tracked single-GPU profile (profiles/r02_configs.json: ms per call of this config at every shard size)
-    predicts for this run, so that a surprising scaling curve can be read against it: strong scaling of a global batch is
-    bounded by the time one shard takes on one GPU, and a shard of 8 images is latency-bound."""
+    predicts for this run, so that a surprising scaling curve can be read against it.  Weak scaling (the same batch on
+    every GPU) adds only the exchange to a step; strong scaling of one batch is bounded by the time ONE SHARD takes on one
+    GPU, and a shard of 8 images is latency-bound."""
     try:
         rows = json.load(open(os.path.join(ROOT, "profiles", "r02_configs.json")))["rows"]
         def row(b):                        # "cfg3_B8_shard_of_8gpu", "cfg2_B1" (= cfg3 at B = 1), ...
@@ -458,17 +481,19 @@ def predict_from_profile(config, global_batch, world, shard, value):
                     if k == "%s_B%d" % (c, b) or k.startswith("%s_B%d_" % (c, b)):
                         return v
             return None
-        full, part = row(global_batch), row(shard)
+        n1_batch = shard if weak else global_batch            # what ONE GPU runs at N = 1 under this scaling mode
+        full, part = row(n1_batch), row(shard)
         if not full or not part:
-            return {"note": "no profile row for %s at B=%d / B=%d" % (config, global_batch, shard)}
-        n1 = global_batch / (full["event_ms_per_call_median"] * 1e-3)
+            return {"note": "no profile row for %s at B=%d / B=%d" % (config, n1_batch, shard)}
+        n1 = n1_batch / (full["event_ms_per_call_median"] * 1e-3)
         pred = global_batch / (part["event_ms_per_call_median"] * 1e-3)           # without the exchange (10-30 us)
         return {"n1_profile_images_per_s": round(n1, 1), "shard_ms_per_call_profile": part["event_ms_per_call_median"],
                 "predicted_images_per_s_without_exchange": round(pred, 1),
                 "predicted_speedup": round(pred / n1, 2), "predicted_efficiency": round(pred / n1 / world, 3),
                 "efficiency_vs_n1_profile": round(value / n1 / world, 3),
                 "measured_over_predicted": round(value / pred, 3),
-                "source": "profiles/r02_configs.json (one MI355X, event_ms_per_call_median of the shard size)"}
+                "source": "profiles/r02_configs.json (round 2, one MI355X, event_ms_per_call_median of the shard size; round 3's "
+                          "staged count makes large shards faster than this profile)"}
     except Exception as e:                                                          # never lose the bench line to this
         return {"note": "prediction unavailable: %s" % (e,)}
 

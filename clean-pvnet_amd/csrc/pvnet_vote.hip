@@ -267,7 +267,11 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     const Bf16Consts fc = bf16_consts(p->inlier_thresh);
     const int target = tuning_int("PVV_TARGET_ITEMS", items_per_cu * num_cus());
     const int target_first = tuning_int("PVV_TARGET_ITEMS_FIRST", target), target_filter = tuning_int("PVV_TARGET_ITEMS_FILTER", target);
-    const int per_cu_first = tuning_int("PVV_GRID_PER_CU_FIRST", per_cu), per_cu_filter = tuning_int("PVV_GRID_PER_CU_FILTER", per_cu);
+    // the second launch's items are short (a few matrix-core tiles behind the same prologue): one generation of blocks
+    // walks them as fast as three (-0.6 % per call at B = 64, -1.8 % at B = 32) and an EMPTY second launch -- a batch of
+    // small masks -- costs a third (-1.5 % on config 4 at B = 32)
+    const int per_cu_first = tuning_int("PVV_GRID_PER_CU_FIRST", per_cu);
+    const int per_cu_filter = tuning_int("PVV_GRID_PER_CU_FILTER", p->hn < 2048 ? 5 : per_cu);
     long long *dbg = tuning_ptr("PVV_DBG_PTR");
     if (!staged) {
         hipLaunchKernelGGL(k_count_bf16<kCountFull>, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,

@@ -27,7 +27,7 @@ def test_bench_under_torchrun_one_rank_executes_the_rccl_exchange(gpu):
     r = subprocess.run(cmd, capture_output=True, text=True, env=_env(), timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["scaling"] == "strong"
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["scaling"] == "weak"
     assert line["extra"]["rccl_ranks"] == 1 and "all_gather_into_tensor" in line["extra"]["exchange"]
     assert line["config"]["global_batch"] == 4 and line["config"]["batch_per_gpu"] == 4
     assert line["value"] > 0 and line["extra"]["known_answer_max_err_px"] < 20
@@ -137,12 +137,13 @@ def test_hip_layer_in_a_world_of_two_ranks_on_one_gpu_uneven_shards(gpu, tmp_pat
 def test_bare_bench_gpus_2_launches_its_own_ranks(gpu):
     """`python bench.py --gpus 2 --steps 3` with NO launcher and no WORLD_SIZE (it used to die on an
     assertion): bench.py starts its ranks under torch.distributed.run itself.  On this 1-GPU box the two ranks share the
-    device and exchange over gloo; shards of 3 + 2 images, weak-scaling and overlapped-exchange legs included."""
+    device and exchange over gloo; --scaling strong cuts the 5 images into shards of 3 + 2; the weak-scaling (5 per rank)
+    and overlapped-exchange legs are included."""
     env = _env()
     for k in ("WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "5",
-           "--rotate", "2", "--prewarm-ms", "20"]
+           "--rotate", "2", "--prewarm-ms", "20", "--scaling", "strong"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -125,19 +125,14 @@ def main():
             del g, gout
         except Exception as ex:  # noqa: BLE001
             graph_ms = "failed: %s" % (str(ex)[:100],)
-        # (e) the count kernel alone
+        # (e) the kernels as they run inside the calls: HIP events at the stage boundaries (pvv_problem.ev_marks).  The count
+        #     pass = one k_count_bf16 launch, or -- staged (AUTO on large batches) -- k_count_bf16<first> + k_lead +
+        #     k_count_bf16<filter>
         _o, win, tn, ws = ext.ransac_voting_v3(mask, vertex, hn, 0.99, 5, max_num, None, None, 1, ext.SINGULAR_REFERENCE)
-        for _ in range(3):
-            ext.rerun_count_kernel(mask, vertex, hn, 0.99, 5, max_num, ws, False)
-        groups, per_group = 5, 10
-        kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(groups)]
-        for a, b in kev:
-            a.record()
-            for _ in range(per_group):
-                ext.rerun_count_kernel(mask, vertex, hn, 0.99, 5, max_num, ws, False)
-            b.record()
-        torch.cuda.synchronize()
-        k_ms = sum(a.elapsed_time(b) / per_group for a, b in kev) / groups
+        st = ext.stage_ms_in_pipeline([mask], [vertex], hn, 0.99, 5, max_num, 1, 36, ext.COUNT_AUTO)[6:]
+        stage_names = ("k_tile_scan", "k_compact_hyp", "count_pass", "k_select_refit", "k_finalize_v3", "count_first_launch", "k_lead")
+        stages = {nm: round(pct([r[j] for r in st], 0.5), 4) for j, nm in enumerate(stage_names) if pct([r[j] for r in st], 0.5) >= 0}
+        k_ms = stages["count_pass"]
         tn_sum = int(tn.sum().item())
         evals = tn_sum * K * hn
         alg = synth.dense_field_bytes(B, H, W, K, hn)
@@ -150,7 +145,8 @@ def main():
                "event_ms_per_call_median": round(pct(per, 0.5), 4), "event_ms_p10": round(pct(per, 0.1), 4),
                "event_ms_p90": round(pct(per, 0.9), 4),
                "graph_replay_ms_per_call": round(graph_ms, 4) if isinstance(graph_ms, float) else graph_ms,
-               "count_kernel_ms": round(k_ms, 4), "evaluations": evals,
+               "count_kernel_ms": round(k_ms, 4), "count_pass_staged": "k_lead" in stages, "kernels_inside_calls_ms": stages,
+               "evaluations": evals,
                "tevals_per_s": round(evals / (k_ms * 1e-3) / 1e12, 2),
                "dense_field_bytes": alg, "roofline_frac_hbm_8TBs": round(alg / (k_ms * 1e-3) / 8e12, 4),
                "known_answer_max_err_px": round(err, 3)}

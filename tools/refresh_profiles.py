@@ -30,15 +30,27 @@ with open(os.path.join(ROOT, "profiles", TAG + "_kernel_stats.csv"), "w") as o:
         if short(r["Name"]):
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 summ = json.load(open(tmp))
-p = summ["pmc"]["k_count_bf16"]
+# the count pass of the profiled workload: one k_count_bf16<0> launch, or -- staged -- <1> + k_lead + <2>
+pass_kernels = [k for k in ("k_count_bf16<1>", "k_lead", "k_count_bf16<2>") if k in summ["pmc"]] or ["k_count_bf16<0>"]
+def kb(kern, name):
+    return summ["pmc"].get(kern, {}).get(name, {}).get("main_mean", 0.0)
+fetch = sum(kb(k, "FETCH_SIZE") for k in pass_kernels)
+write = sum(kb(k, "WRITE_SIZE") for k in pass_kernels)
 pmc_path = os.path.join(ROOT, "profiles", "count_kernel_pmc.json")
 old = json.load(open(pmc_path))
-fetch, write = p["FETCH_SIZE"]["main_mean"], p["WRITE_SIZE"]["main_mean"]
 old.update({"FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "hbm_bytes_per_launch": int((fetch + write) * 1024),
-            "images_per_launch": 64,
+            "images_per_launch": 64, "kernels": pass_kernels,
+            "per_kernel_KB": {k: {"FETCH_SIZE": kb(k, "FETCH_SIZE"), "WRITE_SIZE": kb(k, "WRITE_SIZE")} for k in pass_kernels},
             "source": "%s (tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, python "
-                      "bench.py --steps 20 --warmup 5 --no-cpu-baseline), round tag %s" % (prof, TAG)})
+                      "bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-two-stream), round tag %s; 'launch' = one count "
+                      "pass (the sum over the kernels listed)" % (prof, TAG)})
 json.dump(old, open(pmc_path, "w"), indent=1)
+# the two HBM-facing kernels of the front end (bench.py's roofline_scan / roofline_compact read this)
+front = {"workload": old.get("workload"), "source": old["source"]}
+for kern in ("k_tile_scan", "k_compact_hyp"):
+    front[kern] = {"FETCH_SIZE_KB": kb(kern, "FETCH_SIZE"), "WRITE_SIZE_KB": kb(kern, "WRITE_SIZE"),
+                   "hbm_bytes_per_launch": int((kb(kern, "FETCH_SIZE") + kb(kern, "WRITE_SIZE")) * 1024)}
+json.dump(front, open(os.path.join(ROOT, "profiles", "front_kernels_pmc.json"), "w"), indent=1)
 for a, b in (("bench_default", TAG + "_bench_default"), ("bench_extras", TAG + "_bench_extras"),
              ("bench_torchrun1", TAG + "_bench_torchrun_1rank"), ("bench_under_rocprof", TAG + "_bench_under_rocprof")):
     if not os.path.exists(os.path.join(fin, a + ".json")):
@@ -50,9 +62,10 @@ if os.path.exists(os.path.join(fin, "configs.json")):
 for extra in glob.glob(os.path.join(fin, "gaps_*.json")):
     json.dump(json.load(open(extra)), open(os.path.join(ROOT, "profiles", TAG + "_" + os.path.basename(extra)), "w"), indent=1)
 k = summ["kernel_stats"]
-g = p["GRBM_GUI_ACTIVE"]["main_mean"] / 8
-print("k_count_bf16 avg_us %.2f  VALU insts %.3g  VALU busy %.3f  clock GHz %.2f" % (
-    k["k_count_bf16"]["avg_us"], p["SQ_INSTS_VALU"]["main_mean"], p["SQ_ACTIVE_INST_VALU"]["main_mean"] * 4 / 1024 / g,
-    g / (k["k_count_bf16"]["avg_us"] * 1e3)))
+for kern in pass_kernels:
+    g = kb(kern, "GRBM_GUI_ACTIVE") / 8
+    if g and kern in k:
+        print("%s avg_us %.2f  VALU insts %.3g  VALU busy (of GUI/8 cycles) %.3f" % (
+            kern, k[kern]["avg_us"], kb(kern, "SQ_INSTS_VALU"), kb(kern, "SQ_ACTIVE_INST_VALU") * 4 / 1024 / g))
 for n, v in k.items():
     print("  %-20s %8.2f us" % (n, v["avg_us"]))
