@@ -38,7 +38,7 @@ fetch = sum(kb(k, "FETCH_SIZE") for k in pass_kernels)
 write = sum(kb(k, "WRITE_SIZE") for k in pass_kernels)
 pmc_path = os.path.join(ROOT, "profiles", "count_kernel_pmc.json")
 old = json.load(open(pmc_path))
-old.update({"FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "hbm_bytes_per_launch": int((fetch + write) * 1024),
+old.update({"kernel": " + ".join(pass_kernels), "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "hbm_bytes_per_launch": int((fetch + write) * 1024),
             "images_per_launch": 64, "kernels": pass_kernels,
             "per_kernel_KB": {k: {"FETCH_SIZE": kb(k, "FETCH_SIZE"), "WRITE_SIZE": kb(k, "WRITE_SIZE")} for k in pass_kernels},
             "source": "%s (tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, python "
@@ -46,10 +46,16 @@ old.update({"FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "hbm_bytes_per_launc
                       "pass (the sum over the kernels listed)" % (prof, TAG)})
 json.dump(old, open(pmc_path, "w"), indent=1)
 # the two HBM-facing kernels of the front end (bench.py's roofline_scan / roofline_compact read this)
-front = {"workload": old.get("workload"), "source": old["source"]}
-for kern in ("k_tile_scan", "k_compact_hyp"):
-    front[kern] = {"FETCH_SIZE_KB": kb(kern, "FETCH_SIZE"), "WRITE_SIZE_KB": kb(kern, "WRITE_SIZE"),
-                   "hbm_bytes_per_launch": int((kb(kern, "FETCH_SIZE") + kb(kern, "WRITE_SIZE")) * 1024)}
+front = {"workload": old.get("workload"), "source": old["source"],
+         "calibration": "MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming "
+                        "read -- k_tile_scan is one (8 B per lane, unit stride, read once): 2 x FETCH_SIZE is taken and checks against the "
+                        "known byte count, B*H*W*8 = 157.3 MB of int64 mask at B = 64 (k_stream_read, the probe, shows the same factor: "
+                        "half of its 1.42 GB).  k_compact_hyp gathers 8 B per lane out of 72-byte pixel records: uncalibrated, taken x1.0; "
+                        "WRITE_SIZE x1.0 (its known count: coords + planar dirs of the foreground = 64 x 6144 x 80 B = 31.5 MB + "
+                        "hypotheses and zeroed counters 3.5 MB)"}
+for kern, fmul in (("k_tile_scan", 2.0), ("k_compact_hyp", 1.0)):
+    front[kern] = {"FETCH_SIZE_KB": kb(kern, "FETCH_SIZE"), "WRITE_SIZE_KB": kb(kern, "WRITE_SIZE"), "fetch_correction": fmul,
+                   "hbm_bytes_per_launch": int((fmul * kb(kern, "FETCH_SIZE") + kb(kern, "WRITE_SIZE")) * 1024)}
 json.dump(front, open(os.path.join(ROOT, "profiles", "front_kernels_pmc.json"), "w"), indent=1)
 for a, b in (("bench_default", TAG + "_bench_default"), ("bench_extras", TAG + "_bench_extras"),
              ("bench_torchrun1", TAG + "_bench_torchrun_1rank"), ("bench_under_rocprof", TAG + "_bench_under_rocprof")):
