@@ -289,15 +289,21 @@ def main():
                 torch.cuda.synchronize()
         rewarm()
         reps = 36
-        ms = ext.stage_ms_in_pipeline([d["mask"] for d in batches], [d["vertex"] for d in batches], hn, thresh, 5, 30000, 12, reps,
-                                      ext.COUNT_AUTO)[6:]
-        names = ("k_tile_scan", "k_compact_hyp", "count_pass", "k_select_refit", "k_finalize_v3", "count_stage0", "k_prune")
+        # first without records INSIDE the count pass (they cost ~2 us each): the pass as rocprofv3 sees it; then with them,
+        # for the split of a staged pass into its launches
+        names = ("k_tile_scan", "k_compact_hyp", "count_pass", "k_select_refit", "k_finalize_v3", "count_first_launch", "k_lead")
         stage = {}
-        for j, nm in enumerate(names):
-            col = sorted(r[j] for r in ms if r[j] >= 0)
-            if col:
-                stage[nm] = {"avg_ms": round(sum(col) / len(col), 4), "median_ms": round(col[len(col) // 2], 4)}
-        staged_path = "count_stage0" in stage
+        for inner in (False, True):
+            ms = ext.stage_ms_in_pipeline([d["mask"] for d in batches], [d["vertex"] for d in batches], hn, thresh, 5, 30000, 12, reps,
+                                          ext.COUNT_AUTO, inner)[6:]
+            for j, nm in enumerate(names):
+                if (j >= 5) != inner:
+                    continue
+                col = sorted(r[j] for r in ms if r[j] >= 0)
+                if col:
+                    stage[nm] = {"avg_ms": round(sum(col) / len(col), 4), "median_ms": round(col[len(col) // 2], 4)}
+            rewarm()
+        staged_path = "k_lead" in stage
         k_avg_ms, k_med_ms = stage["count_pass"]["avg_ms"], stage["count_pass"]["median_ms"]
         stage["sum_avg_ms"] = round(sum(stage[nm]["avg_ms"] for nm in names[:5]), 4)
         rewarm()

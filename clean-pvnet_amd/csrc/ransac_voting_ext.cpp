@@ -428,7 +428,8 @@ std::vector<double> count_kernel_ms_in_pipeline(std::vector<at::Tensor> masks, s
 // finalize, (staged only:) first count launch, first prune, 0].  One synchronisation at the end; a measurement aid.
 std::vector<std::vector<double>> stage_ms_in_pipeline(std::vector<at::Tensor> masks, std::vector<at::Tensor> vertices,
                                                       int64_t round_hyp_num, double inlier_thresh, int64_t min_num,
-                                                      int64_t max_num, int64_t seed, int64_t reps, int64_t count_kernel)
+                                                      int64_t max_num, int64_t seed, int64_t reps, int64_t count_kernel,
+                                                      bool inner_marks)
 {
     TORCH_CHECK(!masks.empty() && masks.size() == vertices.size(), "need as many masks as vertex fields");
     const c10::DeviceGuard device_guard(vertices[0].device());
@@ -440,7 +441,11 @@ std::vector<std::vector<double>> stage_ms_in_pipeline(std::vector<at::Tensor> ma
         pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, PVV_SINGULAR_REFERENCE,
                                      seed + r);
         p.count_kernel = (int32_t)count_kernel;
-        p.ev_marks = (void **)&ev[(size_t)PVV_N_MARKS * (size_t)r];
+        std::vector<void *> marks(PVV_N_MARKS);
+        for (int i = 0; i < PVV_N_MARKS; ++i) marks[(size_t)i] = (void *)ev[(size_t)PVV_N_MARKS * (size_t)r + (size_t)i];
+        // inner_marks = false: no records INSIDE the count pass (each costs ~2 us): its duration is then what rocprofv3 sees
+        if (!inner_marks) marks[PVV_MARK_STAGE0] = marks[PVV_MARK_PRUNE0] = nullptr;
+        p.ev_marks = marks.data();
         at::Tensor ws = make_workspace(p, vertex);
         auto out = at::empty({p.B, p.K, 2}, vertex.options());
         ok(pvv_ransac_voting_v3(&p, mask.data_ptr(), vertex.data_ptr<float>(), nullptr, nullptr, ws.data_ptr(),
@@ -534,7 +539,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("stage_ms_in_pipeline", &stage_ms_in_pipeline,
           "per-stage durations inside full v3 calls, HIP events at the stage boundaries (profiling aid)", py::arg("masks"),
           py::arg("vertices"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"),
-          py::arg("seed"), py::arg("reps"), py::arg("count_kernel") = 0);
+          py::arg("seed"), py::arg("reps"), py::arg("count_kernel") = 0, py::arg("inner_marks") = true);
     m.def("stream_read_probe", &stream_read_probe, "one read-once streaming pass over a buffer (bench aid)");
     m.def("count_kernel_ms_in_pipeline", &count_kernel_ms_in_pipeline,
           "duration of the inlier-count kernel inside full v3 calls, HIP events around its launch (profiling aid)",

@@ -204,6 +204,8 @@ def test_stage_marks_and_stream_probe(synth, pkg, gpu):
                 assert 0 < r[5] < r[2] and 0 < r[6] < r[2], r    # first count launch and k_lead inside the count pass
             else:
                 assert r[5] < 0 and r[6] < 0, r                  # not recorded
+        ms2 = ext.stage_ms_in_pipeline([d["mask"]], [d["vertex"]], 512, 0.99, 5, 30000, 1, 4, k, False)
+        assert all(r[5] < 0 and r[6] < 0 and 0 < r[2] < 5 for r in ms2)     # no records inside the count pass on request
     buf = torch.empty(256 << 20, dtype=torch.uint8, device=gpu).random_(0, 255)
     sink = torch.zeros(1, dtype=torch.int32, device=gpu)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

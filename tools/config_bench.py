@@ -129,9 +129,13 @@ def main():
         #     pass = one k_count_bf16 launch, or -- staged (AUTO on large batches) -- k_count_bf16<first> + k_lead +
         #     k_count_bf16<filter>
         _o, win, tn, ws = ext.ransac_voting_v3(mask, vertex, hn, 0.99, 5, max_num, None, None, 1, ext.SINGULAR_REFERENCE)
-        st = ext.stage_ms_in_pipeline([mask], [vertex], hn, 0.99, 5, max_num, 1, 36, ext.COUNT_AUTO)[6:]
         stage_names = ("k_tile_scan", "k_compact_hyp", "count_pass", "k_select_refit", "k_finalize_v3", "count_first_launch", "k_lead")
-        stages = {nm: round(pct([r[j] for r in st], 0.5), 4) for j, nm in enumerate(stage_names) if pct([r[j] for r in st], 0.5) >= 0}
+        stages = {}
+        for inner in (False, True):        # the pass without records inside it; then its split
+            st = ext.stage_ms_in_pipeline([mask], [vertex], hn, 0.99, 5, max_num, 1, 36, ext.COUNT_AUTO, inner)[6:]
+            for j, nm in enumerate(stage_names):
+                if (j >= 5) == inner and pct([r[j] for r in st], 0.5) >= 0:
+                    stages[nm] = round(pct([r[j] for r in st], 0.5), 4)
         k_ms = stages["count_pass"]
         tn_sum = int(tn.sum().item())
         evals = tn_sum * K * hn

@@ -69,7 +69,7 @@ def main():
             ms = med([a.elapsed_time(b) / (args.calls // 6) for a, b in groups])
             outs[name] = [x.cpu() for x in call(0)[:3]]
             st = ext.stage_ms_in_pipeline([d["mask"] for d in batches], [d["vertex"] for d in batches], hn, 0.99, 5, 30000, 7, 24,
-                                          mode)[6:]
+                                          mode, True)[6:]
             cols = ("scan", "compact", "count_pass", "select", "finalize", "stage0", "prune")
             row[name] = {"ms_per_call": round(ms, 4), "images_per_s": round(B / ms * 1e3, 1),
                          **{c: round(med([r[j] for r in st]), 4) for j, c in enumerate(cols) if med([r[j] for r in st]) >= 0}}
