@@ -530,6 +530,20 @@ def extras_leg(extra, data, out, ext, synth, ransac_voting_layer_v3, estimate_vo
         estimate_voting_distribution_with_mean(mask, vertex, mean)
     torch.cuda.synchronize()
     extra["v3_plus_estimate_images_per_s"] = round(B * n2 / (time.perf_counter() - t2), 1)
+    # the estimate's own count kernel (4096 hypotheses, always the full pass: the estimate weighs every hypothesis) as it
+    # runs inside the calls, with its VALU roofline (the call the network makes with test.un_pnp)
+    st = ext.stage_ms_in_pipeline([mask], [vertex], 4096, thresh, 5, 30000, 3, 12, ext.COUNT_AUTO, False, True)[4:]
+    est_ms = sorted(r[2] for r in st)[len(st) // 2]
+    tn_e = ext.ransac_voting_v3(mask, vertex, hn, thresh, 5, 30000, None, None, 1, ext.SINGULAR_REFERENCE)[2].sum().item()
+    evals_e = int(tn_e) * K * 4096
+    clock_ghz = torch.cuda.get_device_properties(dev).clock_rate / 1e6 if hasattr(torch.cuda.get_device_properties(dev), "clock_rate") else 2.4
+    peak_e = N_SIMD * clock_ghz * 1e9 * EVALS_PER_TILE / (VALU_PER_TILE * CYCLES_PER_VALU)
+    extra["estimate_4096_count_kernel"] = {"ms_inside_calls_median": round(est_ms, 4), "evaluations": evals_e,
+                                           "T_evaluations_per_s": round(evals_e / (est_ms * 1e-3) / 1e12, 3),
+                                           "roofline_valu_frac": round(evals_e / (est_ms * 1e-3) / peak_e, 4),
+                                           "scan_ms": round(sorted(r[0] for r in st)[len(st) // 2], 4),
+                                           "compact_hyp_ms": round(sorted(r[1] for r in st)[len(st) // 2], 4),
+                                           "covariance_ms": round(sorted(r[3] for r in st)[len(st) // 2], 4)}
     # the reference's default (non-un_pnp) call, resnet18.py:75: 128 hypotheses on ~100 subsampled pixels
     for _ in range(3):
         ransac_voting_layer_v3(mask, vertex, 128, inlier_thresh=thresh, max_num=100)

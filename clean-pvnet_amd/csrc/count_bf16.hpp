@@ -100,8 +100,8 @@ __device__ __forceinline__ int stage_hypothesis(bf16x8 *sB, int *sCnt, int i, fl
 // (P:160-167), not the counts.  Two launches instead of one:
 //   k_count_bf16<kCountFirst>   every hypothesis over the 512-pixel chunks whose index has a residue (mod M) in `mask`
 //                               -- a quarter of an image's chunks, spread over the object;
-//   k_lead (count_prune.hpp)    four leaders per (image, keypoint) counted EXACTLY over all the other pixels: L* = the
-//                               largest of four exactly known full counts;
+//   k_lead (count_prune.hpp)    two leaders per (image, keypoint): their partial counts plus their SURE inliers among all
+//                               the other pixels = lower bounds of two full counts; L* = the larger;
 //   k_count_bf16<kCountFilter>  the other chunks, but only for hypotheses h with  partial(h) + R >= L*  (R = pixels not
 //                               counted by the first launch): every other hypothesis has full(h) <= partial(h) + R < L*
 //                               <= max and can neither win nor tie.  The filter is evaluated on the fly while a block
@@ -494,9 +494,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                                                        epsw);
                     unsigned qs[2] = {0u, 0u};                        // sign-bit queues, one per 4 tiles (newest evaluation = bit 0)
                     unsigned mb[2] = {0u, 0u};                        // in-band evaluations of flagged tiles: bit 8*(j%4) + e
+                    // ntile_w made opaque per hypothesis tile: the seven "j < ntile_w" below are then scalar compares in
+                    // place instead of seven SGPR pairs computed per item and kept alive across the loop (26 instead of 41
+                    // spilled scalars in the full kernel, 53 instead of 64 in the filter kernel; -0.1 ... -1.4 % per call)
+                    int ntw = ntile_w;
+                    asm volatile("" : "+s"(ntw));
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        if (j < ntile_w) {
+                        if (j < ntw) {
                             const float16v acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j], Bop, zero16, 0, 0, 0);
                             // conservative band test per tile: min |t|  vs  beta * (bound on a) + eps
                             float tmin = INFINITY;

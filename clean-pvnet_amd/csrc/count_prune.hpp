@@ -10,9 +10,10 @@
 // k_count_bf16<kCountFirst> has counted every hypothesis over a spread quarter of an image's 512-pixel chunks, this kernel
 // takes kLead = 2 leaders per (image, keypoint) -- the best two of the four per-wavefront leaders (maximal PARTIAL count
 // among the wave's share of the hypotheses, first index among ties): the overall partial leader is one of them -- and
-// counts them EXACTLY (K:100-125) over every pixel the first launch did not count.  lead[b,k,0..3] = the leaders' partial
-// counts (-1: none), lead[b,k,4..7] = their counts over the rest: exactly known FULL counts, whose maximum L* bounds the
-// winner's count from below.  The
+// counts their SURE inliers over every pixel the first launch did not count (see the loop below: a lower bound of the exact
+// count, without its square roots and divisions).  lead[b,k,0..3] = the leaders' partial counts (-1: none),
+// lead[b,k,4..7] = their sure inliers in the rest: lower bounds of two FULL counts, whose maximum L* bounds the winner's
+// count from below.  The
 // second launch (k_count_bf16<kCountFilter>) then only counts hypotheses with  partial + R >= L*  (count_bf16.hpp).
 //
 // Grid (K * nsplit, B): the remaining pixels of an (image, keypoint) are cut into nsplit shares so that the whole batch is
@@ -31,7 +32,7 @@ struct LeadArgs {
     int *lead;               // [B,K,8]
     const int *any_staged;   // one word written by k_count_bf16<kCountFirst>: 0 = no image of the batch is staged
     int K, hn, cap;
-    float thresh;
+    float kappa, beta, eps;  // the sure-inlier test below: kappa = T/sqrt(1-T^2), band = 2 x the count kernel's second level
     int nsplit;
 };
 
@@ -56,16 +57,16 @@ __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
     const int r1 = min(rem_px, (split + 1) * per);
     const float2 *crd = a.coords + (size_t)b * a.cap;
     const float2 *dir = a.dirs + (size_t)bk * a.cap;
-    float2 cc[kTrip], dd[kTrip];
+    float2 cc[kTrip], dd_[kTrip];
     auto load_trip = [&](int r0) {
 #pragma unroll
         for (int u = 0; u < kTrip; ++u) {
             const int r = r0 + u * kBlock;
-            cc[u] = dd[u] = make_float2(0.f, 0.f);                 // zero direction: norm1 < 1e-6, never an inlier
+            cc[u] = dd_[u] = make_float2(0.f, 0.f);                // zero direction: never an inlier
             if (r < r1) {
                 const int p = stage_chunk_at<kStageRest>(r / PC) * PC + (r & (PC - 1));
                 cc[u] = crd[p];
-                dd[u] = dir[p];
+                dd_[u] = dir[p];
             }
         }
     };
@@ -108,15 +109,34 @@ __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
         for (int w = 0; w < kLead; ++w) if ((int)threadIdx.x == w) v = lc[w];
         a.lead[(size_t)bk * 8 + threadIdx.x] = v;                  // slots kLead..3: no leader
     }
+    // ---- SURE inliers only.  L* has to be a LOWER bound of the winner's count, nothing more: a leader's partial count plus
+    //      the pixels of the rest that are inliers BEYOND DOUBT is one (<= its exact full count <= the maximum), and it needs
+    //      neither the correctly rounded square roots and divisions of the exact vote (~50 VALU instructions per pixel and
+    //      leader: two leaders made this kernel VALU-bound at 15 us) nor a fallback.  The test is the count kernel's second
+    //      level (count_bf16.hpp: t = a - kappa |d x nh| against a guard band) with the unit normal from
+    //      v_rsq_f32 (<= 3u relative, what that band assumes of an f32 normal) and TWICE its band: |t| - 2 beta2 a > 2 eps0
+    //      and t > 0.  Pixels the exact vote rejects outright (K:121: norm1 < 1e-6, non-finite directions) have dd <= 4e-12
+    //      or dd = inf/NaN and are not counted; what the band excludes (a few 1e-5 of the pixels) only lowers the bound.
     int inl[kLead];
 #pragma unroll
     for (int w = 0; w < kLead; ++w) inl[w] = 0;
     for (;;) {
 #pragma unroll
-        for (int u = 0; u < kTrip; ++u)
+        for (int u = 0; u < kTrip; ++u) {
+            const float dd = dd_[u].x * dd_[u].x + dd_[u].y * dd_[u].y;
+            const bool ok = dd > 4e-12f && dd < INFINITY;
+            const float r = __builtin_amdgcn_rsqf(dd);
+            const float nx = dd_[u].x * r, ny = dd_[u].y * r;
+            const float bx = -a.kappa * ny, by = a.kappa * nx;
 #pragma unroll
-            for (int w = 0; w < kLead; ++w)
-                inl[w] += vote_exact(cc[u].x, cc[u].y, ld[w].x, ld[w].y, dd[u].x, dd[u].y, a.thresh) ? 1 : 0;
+            for (int w = 0; w < kLead; ++w) {
+                const float dx = ld[w].x - cc[u].x, dy = ld[w].y - cc[u].y;
+                const float av = __builtin_fmaf(dx, nx, dy * ny);
+                const float bv = __builtin_fmaf(dx, bx, dy * by);
+                const float t = av - fabsf(bv);
+                inl[w] += (ok && t > 0.f && __builtin_fmaf(-a.beta, av, t) > a.eps) ? 1 : 0;
+            }
+        }
         r0 += kTrip * kBlock;
         if (r0 - (int)threadIdx.x >= r1) break;                    // block-uniform
         load_trip(r0);

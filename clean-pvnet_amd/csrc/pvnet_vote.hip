@@ -290,7 +290,8 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     if (int e = mark(p, PVV_MARK_STAGE0, st)) return e;
     LeadArgs la;
     la.tn_arr = tn; la.coords = coords; la.dirs = dirs; la.hyps = hyps; la.counts = counts; la.lead = lead;
-    la.K = p->K; la.hn = p->hn; la.cap = p->cap; la.thresh = p->inlier_thresh;
+    la.K = p->K; la.hn = p->hn; la.cap = p->cap;
+    la.kappa = fc.kappa; la.beta = 2.f * fc.beta2; la.eps = 2.f * fc.eps0;
     la.any_staged = sa.any_staged;
     // shares per (image, keypoint): the largest power of two <= 16 that keeps the grid within one generation of blocks
     // (8 per CU)

@@ -429,7 +429,7 @@ std::vector<double> count_kernel_ms_in_pipeline(std::vector<at::Tensor> masks, s
 std::vector<std::vector<double>> stage_ms_in_pipeline(std::vector<at::Tensor> masks, std::vector<at::Tensor> vertices,
                                                       int64_t round_hyp_num, double inlier_thresh, int64_t min_num,
                                                       int64_t max_num, int64_t seed, int64_t reps, int64_t count_kernel,
-                                                      bool inner_marks)
+                                                      bool inner_marks, bool estimate)
 {
     TORCH_CHECK(!masks.empty() && masks.size() == vertices.size(), "need as many masks as vertex fields");
     const c10::DeviceGuard device_guard(vertices[0].device());
@@ -448,9 +448,19 @@ std::vector<std::vector<double>> stage_ms_in_pipeline(std::vector<at::Tensor> ma
         p.ev_marks = marks.data();
         at::Tensor ws = make_workspace(p, vertex);
         auto out = at::empty({p.B, p.K, 2}, vertex.options());
-        ok(pvv_ransac_voting_v3(&p, mask.data_ptr(), vertex.data_ptr<float>(), nullptr, nullptr, ws.data_ptr(),
-                                (size_t)ws.numel(), out.data_ptr<float>(), nullptr, nullptr, cur_stream(vertex)),
-           "ransac_voting_v3");
+        if (estimate) {      // estimate_voting_distribution_with_mean with round_hyp_num hypotheses in total (mean = zeros: timing only)
+            out.zero_();
+            auto cov = at::empty({p.B, p.K, 2, 2}, vertex.options());
+            ok(pvv_estimate_voting_distribution(&p, mask.data_ptr(), vertex.data_ptr<float>(), nullptr, nullptr, out.data_ptr<float>(),
+                                                ws.data_ptr(), (size_t)ws.numel(), cov.data_ptr<float>(), nullptr, nullptr, nullptr,
+                                                nullptr, cur_stream(vertex)),
+               "estimate_voting_distribution");
+            keep.push_back(cov);
+        } else {
+            ok(pvv_ransac_voting_v3(&p, mask.data_ptr(), vertex.data_ptr<float>(), nullptr, nullptr, ws.data_ptr(),
+                                    (size_t)ws.numel(), out.data_ptr<float>(), nullptr, nullptr, cur_stream(vertex)),
+               "ransac_voting_v3");
+        }
         keep.push_back(ws);
         keep.push_back(out);
     }
@@ -467,8 +477,8 @@ std::vector<std::vector<double>> stage_ms_in_pipeline(std::vector<at::Tensor> ma
         ms[(size_t)r][0] = dt(PVV_MARK_BEGIN, PVV_MARK_SCAN);
         ms[(size_t)r][1] = dt(PVV_MARK_SCAN, PVV_MARK_COMPACT);
         ms[(size_t)r][2] = dt(PVV_MARK_COMPACT, PVV_MARK_COUNT);
-        ms[(size_t)r][3] = dt(PVV_MARK_COUNT, PVV_MARK_SELECT);
-        ms[(size_t)r][4] = dt(PVV_MARK_SELECT, PVV_MARK_END);
+        ms[(size_t)r][3] = estimate ? dt(PVV_MARK_COUNT, PVV_MARK_END) : dt(PVV_MARK_COUNT, PVV_MARK_SELECT);   // estimate: k_covariance
+        ms[(size_t)r][4] = estimate ? 0.0 : dt(PVV_MARK_SELECT, PVV_MARK_END);
         ms[(size_t)r][5] = dt(PVV_MARK_COMPACT, PVV_MARK_STAGE0);
         ms[(size_t)r][6] = dt(PVV_MARK_STAGE0, PVV_MARK_PRUNE0);
     }
@@ -539,7 +549,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("stage_ms_in_pipeline", &stage_ms_in_pipeline,
           "per-stage durations inside full v3 calls, HIP events at the stage boundaries (profiling aid)", py::arg("masks"),
           py::arg("vertices"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"),
-          py::arg("seed"), py::arg("reps"), py::arg("count_kernel") = 0, py::arg("inner_marks") = true);
+          py::arg("seed"), py::arg("reps"), py::arg("count_kernel") = 0, py::arg("inner_marks") = true, py::arg("estimate") = false);
     m.def("stream_read_probe", &stream_read_probe, "one read-once streaming pass over a buffer (bench aid)");
     m.def("count_kernel_ms_in_pipeline", &count_kernel_ms_in_pipeline,
           "duration of the inlier-count kernel inside full v3 calls, HIP events around its launch (profiling aid)",

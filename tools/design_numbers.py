@@ -69,4 +69,14 @@ for k, v in vals.items():
     sec = sec.replace('{{' + k + '}}', v)
 assert '{{' not in sec, sec[sec.index('{{'):sec.index('{{') + 30]
 s = s[:a] + sec + "\n" + s[b:]
+# section 4.6: the three launches of the staged pass (last cell of their table rows) and their sum
+import re
+for key, val in (("`k_count_bf16<first>` |", parts[0]), ("`k_lead` (`count_prune.hpp`) |", parts[1]), ("`k_count_bf16<filter>` |", parts[2])):
+    i = s.index("| " + key)
+    j = s.index("\n", i)
+    line = s[i:j]
+    line = re.sub(r"\| [^|]*\|$", "| %.1f |" % val, line)
+    s = s[:i] + line + s[j:]
+s = re.sub(r"Sum [0-9.]+ µs against 187 µs for the full kernel on the same box \(−[0-9]+ %\)",
+           "Sum %.0f µs against 187 µs for the full kernel on the same box (−%.0f %%)" % (sum(parts), 100 * (1 - sum(parts) / 187.0)), s)
 open(p, 'w').write(s)
