@@ -118,8 +118,9 @@ __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
     //      and t > 0.  Pixels the exact vote rejects outright (K:121: norm1 < 1e-6, non-finite directions) have dd <= 4e-12
     //      or dd = inf/NaN and are not counted; what the band excludes (a few 1e-5 of the pixels) only lowers the bound.
     int inl[kLead];
-#pragma unroll
-    for (int w = 0; w < kLead; ++w) inl[w] = 0;
+    bool lnear[kLead];       // a leader beyond 1e15 px (or non-finite) gets no sure inliers: the exact vote's squares overflow
+#pragma unroll               // out there (norm2 = inf: never an inlier) and this test's do not -- its partial count alone is a bound
+    for (int w = 0; w < kLead; ++w) { inl[w] = 0; lnear[w] = fabsf(ld[w].x) < 1e15f && fabsf(ld[w].y) < 1e15f; }
     for (;;) {
 #pragma unroll
         for (int u = 0; u < kTrip; ++u) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
                 const float av = __builtin_fmaf(dx, nx, dy * ny);
                 const float bv = __builtin_fmaf(dx, bx, dy * by);
                 const float t = av - fabsf(bv);
-                inl[w] += (ok && t > 0.f && __builtin_fmaf(-a.beta, av, t) > a.eps) ? 1 : 0;
+                inl[w] += (ok && lnear[w] && t > 0.f && __builtin_fmaf(-a.beta, av, t) > a.eps) ? 1 : 0;
             }
         }
         r0 += kTrip * kBlock;

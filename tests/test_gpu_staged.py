@@ -161,6 +161,36 @@ def test_staged_count_with_ties_empty_images_and_few_chunks(oracle, synth, pkg, 
     assert want_win[4, 2] == 0 and (want[4, 2] == 0).all()
 
 
+@pytest.mark.parametrize("outlier,sigma", [((0.45, 0.6), 0.05), ((0.0, 0.0), 0.5), ((0.7, 0.8), 0.1)])
+def test_staged_count_when_the_bound_barely_bites(oracle, synth, pkg, gpu, outlier, sigma):
+    """Fields on which the winner explains half of the pixels or fewer (40-80 % outlier pixels, or 0.5 rad of direction
+    noise) on masks large enough to be staged (12+ chunks): after a quarter of the pixels the elimination drops little or
+    nothing -- the regime where a wrong bound would drop the winner.  Staged == full == exact, bit for bit, and the oracle's
+    winners."""
+    from clean_pvnet_amd import ransac_voting as ext
+    c = {**synth.CONFIGS["cfg2"], "B": 3, "outlier": outlier, "sigma": sigma}
+    d = synth.make_batch(**c, seed=321)
+    mask, vertex = d["mask"], d["vertex"]
+    tn = [int(x) for x in (mask != 0).sum((1, 2))]
+    assert min(tn) >= 8 * 512
+    hn, K = 512, c["K"]
+    idxs = synth.make_idxs(tn, hn, K, seed=322)
+    m, v, i = mask.to(gpu), vertex.to(gpu), idxs.to(gpu)
+    res = {}
+    for name, k in _modes(ext):
+        out, win, t2, _ws = ext.ransac_voting_v3(m, v, hn, 0.99, 5, 30000, i, None, 0, ext.SINGULAR_ZERO, count_kernel=k)
+        res[name] = (out.cpu(), win.cpu(), t2.cpu())
+    for name in ("auto", "staged", "full"):
+        for a_, b_ in zip(res[name], res["exact"]):
+            assert torch.equal(a_, b_), name
+    det = []
+    want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, 0.99, idxs=_np(idxs), singular="zero", details=det)
+    np.testing.assert_array_equal(_np(res["staged"][1]), np.stack([r["win_counts"] for r in det]))
+    tol.assert_means_close(_np(res["staged"][0]), want)
+    ratio = np.stack([r["win_counts"] for r in det]).max() / max(tn)
+    assert ratio < 0.75                                  # the winners really are weak here
+
+
 def test_status_flags_truncated_skipped_subsampled(synth, pkg, gpu):
     """pvv_problem.d_status (ABI v6): a list longer than the `cap` rows reserved is cut -- now
     reported --, an image below min_num is SKIPPED, an image above max_num SUBSAMPLED."""
