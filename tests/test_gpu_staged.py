@@ -139,6 +139,14 @@ def test_staged_count_with_ties_empty_images_and_few_chunks(oracle, synth, pkg, 
     keep[100:110, 100:140] = 1
     mask[3] = mask[3] * keep                              # <= 400 px: one chunk
     vertex[4, :, :, 2, :] = 0.0                           # keypoint 2 of image 4: zero directions, never an inlier
+    # non-finite and astronomically large directions on a tenth of image 0's foreground (keypoints 0 and 1): hypotheses
+    # drawn from them are NaN / inf / far away -- the count kernels send their groups down the exact loop, k_lead gives such
+    # a leader no sure inliers
+    ys, xs = torch.nonzero(mask[0], as_tuple=True)
+    pick = torch.arange(0, ys.numel(), 10)
+    vertex[0, ys[pick[0::3]], xs[pick[0::3]], 0, 0] = float("nan")
+    vertex[0, ys[pick[1::3]], xs[pick[1::3]], 0, 1] = float("inf")
+    vertex[0, ys[pick[2::3]], xs[pick[2::3]], 1, :] *= 1e25
     tn = [int(x) for x in (mask != 0).sum((1, 2))]
     assert tn[1] == 0 and tn[2] == 3 and 0 < tn[3] <= 512 and tn[0] > 2048
     hn, K = 256, c["K"]
