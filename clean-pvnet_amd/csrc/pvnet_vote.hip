@@ -166,12 +166,12 @@ bool use_bf16_count(const pvv_problem *p)
 // may stage takes the staged path.  PVV_COUNT_STAGED forces it wherever the matrix-core kernel is valid, PVV_COUNT_FULL
 // forbids it, AUTO stages when the batch is large enough for the two extra launches (k_lead + the second count launch)
 // to pay.  The host knows neither tn nor the winners' inlier ratios, so the rule is a proxy for the evaluations of a full
-// pass, B*K*hn*H*W >= 3e10 -- measured on MI355X (tools/staged_ab.py): 480x640, K = 9, 512 hypotheses breaks even at
+// pass, B*K*hn*H*W >= 2e10 -- measured on MI355X (tools/staged_ab.py): 480x640, K = 9, 512 hypotheses breaks even at
 // B = 16 (2.3e10), +4 % at B = 32, +24 % at B = 64; 540x720, K = 17, 2048 hypotheses at B = 16 (2.2e11) +86 % -- and the
 // DEVICE refines it per image: images of fewer than 8 chunks (tn <= 3584) are counted completely by the first launch, and
 // when no image of the batch is staged the two later launches leave at their first instruction (config 4's sparse masks
 // at B = 32: the call then costs ~5 us more than the full pass, the price of not knowing tn on the host).
-constexpr double kStageMinWork = 3e10;
+constexpr double kStageMinWork = 2e10;
 bool may_stage(const pvv_problem *p)
 {
     if (!use_bf16_count(p) || p->count_kernel == PVV_COUNT_FULL) return false;

@@ -79,4 +79,19 @@ for key, val in (("`k_count_bf16<first>` |", parts[0]), ("`k_lead` (`count_prune
     s = s[:i] + line + s[j:]
 s = re.sub(r"Sum [0-9.]+ µs against 187 µs for the full kernel on the same box \(−[0-9]+ %\)",
            "Sum %.0f µs against 187 µs for the full kernel on the same box (−%.0f %%)" % (sum(parts), 100 * (1 - sum(parts) / 187.0)), s)
+# section 4.6: the full-vs-staged table from profiles/r03_staged_ab.json
+ab = {r['case']: r for r in json.load(open('profiles/r03_staged_ab.json'))}
+notes = {'cfg3:8': 'not staged by AUTO (two extra launches on a latency-bound call)', 'cfg3:16': 'staged by AUTO from here on (2.3·10¹⁰)',
+         'cfg3:32': '', 'cfg3:64': '**the benchmark workload**',
+         'cfg4:32': 'staged by AUTO, nothing to stage (tn ≈ 0.5–2 k: every image below 8 chunks): the first launch counts everything, `k_lead` and the filter launch find the `any_staged` word 0 and leave at once — the price of the host not knowing `tn`',
+         'cfg5:16': '540×720, K = 17, 2048 hypotheses, tn = 30 000'}
+label = {'cfg3:8': 'config 3, B = 8', 'cfg3:16': 'config 3, B = 16', 'cfg3:32': 'config 3, B = 32', 'cfg3:64': 'config 3, **B = 64**',
+         'cfg4:32': 'config 4, B = 32', 'cfg5:16': 'config 5, B = 16'}
+rows = ["| Case | full ms/call | staged ms/call | AUTO ms/call | staged vs full | |", "|---|---|---|---|---|---|"]
+for k in ('cfg3:8', 'cfg3:16', 'cfg3:32', 'cfg3:64', 'cfg4:32', 'cfg5:16'):
+    r = ab[k]
+    rows.append("| %s | %.4f | %.4f | %.4f | %+.0f %% | %s |" % (label[k], r['full']['ms_per_call'], r['staged']['ms_per_call'], r['auto']['ms_per_call'],
+                                                               100 * (r['full']['ms_per_call'] / r['staged']['ms_per_call'] - 1), notes[k]))
+ta, tb = s.index('<!-- staged_ab_table -->'), s.index('<!-- /staged_ab_table -->')
+s = s[:ta] + '<!-- staged_ab_table -->\n' + "\n".join(rows) + '\n' + s[tb:]
 open(p, 'w').write(s)
