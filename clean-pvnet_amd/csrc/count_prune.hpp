@@ -1,4 +1,4 @@
-// count_prune.hpp -- stage 3, between the two launches of the staged count: the leaders' exact full counts
+// count_prune.hpp -- stage 3, between the two launches of the staged count: a lower bound L* of the winner's count
 // (ransac_voting_layer_v3 only).
 // Part of the single translation unit pvnet_vote.hip (included inside its anonymous namespace); see that file
 // for the numerical contract and the reference citations (K = ransac_voting_kernel.cu, P = ransac_voting_gpu.py).
@@ -13,15 +13,16 @@
 // counts their SURE inliers over every pixel the first launch did not count (see the loop below: a lower bound of the exact
 // count, without its square roots and divisions).  lead[b,k,0..3] = the leaders' partial counts (-1: none),
 // lead[b,k,4..7] = their sure inliers in the rest: lower bounds of two FULL counts, whose maximum L* bounds the winner's
-// count from below.  The
-// second launch (k_count_bf16<kCountFilter>) then only counts hypotheses with  partial + R >= L*  (count_bf16.hpp).
+// count from below.  The second launch (k_count_bf16<kCountFilter>) then only counts hypotheses with  partial + R >= L*
+// (count_bf16.hpp).
 //
 // Grid (K * nsplit, B): the remaining pixels of an (image, keypoint) are cut into nsplit shares so that the whole batch is
-// ONE generation of blocks (<= 8 per CU); a thread sees ~10 pixels, all four leaders per pixel, and all its loads are in
+// ONE generation of blocks (<= 8 per CU); a thread sees ~10 pixels, both leaders per pixel, and all its loads are in
 // flight together; the shares add their sums to lead[..4..7] with one atomic each (zeroed by k_compact_hyp).  One block per
 // (image, keypoint) that also compacted the survivors -- the first form of round 3 -- took 36 us at B = 64 (18 dependent
 // memory round trips per block), 4608 short blocks of 2-3 pixels per thread 28 us (two and a half generations of blocks,
-// five round trips each).
+// five round trips each); one generation with the EXACT vote for four / two leaders 24.7 / 15.0 us (VALU-bound: ~50
+// instructions per pixel and leader), with the sure-inlier test below 11 us.
 // ---------------------------------------------------------------------------------------------
 struct LeadArgs {
     const int *tn_arr;
@@ -36,7 +37,7 @@ struct LeadArgs {
     int nsplit;
 };
 
-constexpr int kLead = 2;     // leaders counted exactly per (image, keypoint), <= 4
+constexpr int kLead = 2;     // leaders per (image, keypoint), <= 4
 
 __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
 {
@@ -86,9 +87,8 @@ __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
     }
     if (lane == 0) { s_cnt[wave] = best; s_idx[wave] = besth; }
     __syncthreads();
-    // the best kLead of the four per-wave leaders (count descending, index ascending): the exact vote costs ~50 VALU
-    // instructions per (pixel, leader) -- four leaders made this kernel VALU-bound at 25 us, and the bound L* is the
-    // overall partial leader's full count in nearly every case
+    // the best kLead of the four per-wave leaders (count descending, index ascending); the bound L* comes from the overall
+    // partial leader in nearly every case, the second one is insurance on noisy fields
     int lc[4], li[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) { lc[w] = s_cnt[w]; li[w] = s_idx[w]; }
