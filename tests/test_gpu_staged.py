@@ -199,6 +199,37 @@ def test_staged_count_when_the_bound_barely_bites(oracle, synth, pkg, gpu, outli
     assert ratio < 0.75                                  # the winners really are weak here
 
 
+def test_staged_count_beyond_64_images(oracle, synth, pkg, gpu):
+    """More images than one wavefront scans at a time (the item table and the staged / small bitmap of the count kernels
+    are built 64 images per round): 70 images, some of them below 8 chunks (counted completely by the first launch) between
+    staged ones, one empty."""
+    from clean_pvnet_amd import ransac_voting as ext
+    B, H, W, K, hn = 70, 96, 96, 2, 96
+    d = synth.make_batch(B=B, H=H, W=W, K=K, fg=0.6, sigma=0.05, seed=4100)
+    mask, vertex = d["mask"].clone(), d["vertex"]
+    for bi in range(0, B, 7):                              # every seventh image small: <= 7 chunks
+        keep = torch.zeros_like(mask[bi])
+        keep[20:70, 20:80] = 1
+        mask[bi] = mask[bi] * keep
+    mask[33] = 0
+    tn = [int(x) for x in (mask != 0).sum((1, 2))]
+    assert max(tn) > 8 * 512 and 0 < tn[0] <= 7 * 512 and tn[33] == 0
+    idxs = synth.make_idxs(tn, hn, K, seed=4101)
+    m, v, i = mask.to(gpu), vertex.to(gpu), idxs.to(gpu)
+    res = {}
+    for name, k in _modes(ext):
+        out, win, t2, _ws = ext.ransac_voting_v3(m, v, hn, 0.99, 5, 30000, i, None, 0, ext.SINGULAR_ZERO, count_kernel=k)
+        res[name] = (out.cpu(), win.cpu(), t2.cpu())
+    for name in ("auto", "staged", "full"):
+        for a_, b_ in zip(res[name], res["exact"]):
+            assert torch.equal(a_, b_), name
+    det = []
+    want = oracle.ransac_voting_layer_v3(_np(mask), _np(vertex), hn, 0.99, idxs=_np(idxs), singular="zero", details=det)
+    want_win = np.stack([r["win_counts"] if not r["skipped"] else np.zeros(K, np.int32) for r in det])
+    np.testing.assert_array_equal(_np(res["staged"][1]), want_win)
+    tol.assert_means_close(_np(res["staged"][0]), want)
+
+
 def test_status_flags_truncated_skipped_subsampled(synth, pkg, gpu):
     """pvv_problem.d_status (ABI v6): a list longer than the `cap` rows reserved is cut -- now
     reported --, an image below min_num is SKIPPED, an image above max_num SUBSAMPLED."""
