@@ -176,7 +176,10 @@ bool may_stage(const pvv_problem *p)
 {
     if (!use_bf16_count(p) || p->count_kernel == PVV_COUNT_FULL) return false;
     if (p->count_kernel == PVV_COUNT_STAGED) return true;
-    return p->hn >= 128 && (double)p->B * p->K * p->hn * p->H * p->W >= kStageMinWork;
+    // cap bounds tn: with fewer than 8 chunks of rows reserved per image nothing can ever be staged (the reference's default
+    // call, max_num = 100: 244 rows)
+    return p->hn >= 128 && p->cap >= kStageMinChunks * 4 * kBfPixPerWave &&
+           (double)p->B * p->K * p->hn * p->H * p->W >= kStageMinWork;
 }
 
 Bf16Consts bf16_consts(float thresh)
