@@ -504,7 +504,8 @@ def test_decode_keypoint_beyond_1024_images_and_sharding_invariance(synth, pkg, 
         assert float((whole["kpt_2d"][:8].cpu() - d["kpt_2d"]).abs().max()) < 4.0
 
 
-@pytest.mark.parametrize("max_num,byte_mask", [(30000, False), (5000, False), (2000, False), (30000, True), (48960, True)])
+@pytest.mark.parametrize("max_num,byte_mask", [(30000, False), (5000, False), (2000, False), (30000, True), (48960, True),
+                                               (30001, True)])
 def test_device_rng_draws_replayed_through_the_oracle(oracle, synth, pkg, gpu, max_num, byte_mask):
     """The hypothesis blocks of k_compact_hyp with the DEVICE RNG (no injected index pairs -- the path production
     runs): pvv_problem.d_draws_out reports the pixel every draw resolved to; mapping those pixels to rows of the
@@ -523,6 +524,11 @@ def test_device_rng_draws_replayed_through_the_oracle(oracle, synth, pkg, gpu, m
     mask, vertex = d["mask"].to(gpu), d["vertex"].to(gpu)
     B, H, W, K, hn = 2, 240, 320, c["K"], 256
     sel = torch.rand(B, H, W, generator=torch.Generator().manual_seed(5))          # injected: the oracle needs the same draws
+    if max_num == 30001:
+        # an injected selection may keep ANY number of pixels.  Draws of zero keep every one of the 9216 foreground
+        # pixels although the survival probability is 0.013 (< 1/64: the survivor-list path) -- more than the list's 8192
+        # entries: the hypothesis blocks must fall back to rejection sampling over ALL survivors, not sample a truncated list
+        sel = torch.zeros(B, H, W)
     L = capi.load()
     draws = torch.full((B, K, hn, 2), -7, dtype=torch.int32, device=gpu)
     p = capi.problem(mask, vertex, hn, 0.99, max_num=max_num, seed=2024, draws_out=draws, cap=H * W)
@@ -541,14 +547,17 @@ def test_device_rng_draws_replayed_through_the_oracle(oracle, synth, pkg, gpu, m
     for bi in range(B):
         fg, coords, direct = oracle.compact_v3(_np(mask[bi]), _np(vertex[bi]), max_num, _np(sel[bi]))
         assert coords.shape[0] == int(tn[bi]) and (fg > max_num) == (max_num < 30000 or byte_mask)
-        assert not byte_mask or (60 < coords.shape[0] < 200 if max_num == 30000 else 120 < coords.shape[0] < 280)
+        assert not byte_mask or (60 < coords.shape[0] < 200 if max_num == 30000 else
+                                 (coords.shape[0] > 8192 if max_num == 30001 else 120 < coords.shape[0] < 280))
         row = -np.ones(H * W, np.int64)
         row[(coords[:, 1] * W + coords[:, 0]).astype(np.int64)] = np.arange(coords.shape[0])
         r = row[dr[bi]]                                            # [K,hn,2]
         assert (r >= 0).all(), "a draw resolved to a pixel that did not survive the subsample"
         idxs[bi] = r.transpose(1, 0, 2)
         # the draws are spread over the whole list (uniform index pairs, not stuck on a tile)
-        assert len(np.unique(r)) > 0.5 * min(coords.shape[0], hn * K) or byte_mask
+        assert len(np.unique(r)) > 0.5 * min(coords.shape[0], hn * K) or (byte_mask and max_num != 30001)
+        if max_num == 30001:
+            assert r.max() > 8192                                  # rows beyond the survivor list's capacity are drawn too
     _check_v3(oracle, out, win, tn, mask, vertex, torch.from_numpy(idxs), hn, 0.99, selection=sel, max_num=max_num)
 
 
