@@ -123,3 +123,78 @@ def test_split_bf16_prefilter_band(T):
     ex = exact_decision(cx, cy, hx, hy, nx, ny, T)
     assert outside.mean() > 0.1
     assert np.array_equal((t > 0)[outside], ex[outside])
+
+
+@pytest.mark.parametrize("T", [0.6, 0.9, 0.99, 0.999, 0.9999])
+def test_lead_sure_inlier_test_is_a_lower_bound(T):
+    """k_lead (count_prune.hpp): a pixel is counted for a leader only if it is an inlier BEYOND DOUBT -- the second-level
+    test with the unit normal from v_rsq_f32 and twice the second level's band.  Claim: sure => the exact binary32 vote
+    (K:100-125) accepts it, so the sum is a lower bound of the leader's exact count.  rsq is modelled as the correctly
+    rounded 1/sqrt perturbed by an adversarial +-1 ulp (its documented accuracy); samples straddle the threshold far more
+    closely than the band."""
+    n = 2_000_000
+    Td = np.float64(f32(T)); s2 = 1 - Td * Td; kappa = Td / np.sqrt(s2)
+    beta2 = 1.25 * (6 * (1 + kappa) + 8 / s2) * U / Td
+    beta, eps = f32(2 * f32(beta2)), f32(2 * f32(1.5e-6 * (1 + kappa)))
+    kf = f32(kappa)
+    cx, cy, hx, hy, nx, ny = samples(n, T, 21, spread=6 * 2 * beta2 * Td * np.sqrt(s2) / np.arccos(Td))
+    rng = np.random.RandomState(22)
+    with np.errstate(all="ignore"):
+        dd = nx * nx + ny * ny                                              # binary32, as the kernel
+        r = (1.0 / np.sqrt(dd.astype(np.float64))).astype(f32)
+        r = np.nextafter(r, np.where(rng.rand(n) < 0.5, f32(np.inf), f32(-np.inf)).astype(f32))   # +-1 ulp
+        ok = (dd > f32(4e-12)) & (dd < f32(np.inf))
+        ux, uy = nx * r, ny * r
+        bx, by = -kf * uy, kf * ux
+        dx, dy = hx - cx, hy - cy
+        a = fma32(dx, ux, dy * uy)
+        b = fma32(dx, bx, dy * by)
+        t = a - np.abs(b)
+        sure = ok & (t > 0) & (fma32(np.full(n, -beta, f32), a, t) > eps)
+    ex = exact_decision(cx, cy, hx, hy, nx, ny, T)
+    assert sure.mean() > 0.1 and (ex & ~sure).mean() > 0.005                # plenty of sure ones, plenty left in doubt
+    assert not (sure & ~ex).any()                                          # never counts what the exact vote rejects
+    # tiny and huge directions: what the exact vote rejects outright (norm1 < 1e-6) is never sure
+    tiny = f32(rng.uniform(0, 1.5e-6, n))
+    ang = rng.uniform(0, 2 * np.pi, n)
+    nx2, ny2 = (tiny * np.cos(ang)).astype(f32), (tiny * np.sin(ang)).astype(f32)
+    with np.errstate(all="ignore"):
+        dd2 = nx2 * nx2 + ny2 * ny2
+    ok2 = (dd2 > f32(4e-12)) & (dd2 < f32(np.inf))
+    ex2 = exact_decision(cx, cy, hx, hy, nx2, ny2, T)
+    assert not (ok2 & ~(np.sqrt(nx2 * nx2 + ny2 * ny2) > f32(1e-6))).any() and not (ex2 & ~ok2).sum() > ex2.sum()  # ok2 => norm1 > 1e-6
+
+
+def test_staged_elimination_never_drops_a_winner():
+    """The elimination rule itself on random count tables: partial counts over a part S of the
+    pixels, L* = ANY lower bound of a leader's full count (here: partial + a random share of its true rest), keep h iff
+    partial(h) + R >= L*.  Every hypothesis with the maximal full count is kept -- in particular the first one -- and a
+    dropped hypothesis' partial count is below the maximum."""
+    rng = np.random.RandomState(3)
+    for trial in range(2000):
+        hn = int(rng.choice([32, 100, 512]))
+        tn = int(rng.randint(600, 8000))
+        nS = int(tn * rng.uniform(0.1, 0.6))
+        rho = rng.uniform(0.05, 1.0, hn) ** rng.choice([0.3, 1.0, 3.0])     # true inlier ratios, varied shapes
+        if trial % 3 == 0:
+            rho[rng.randint(hn, size=3)] = rho.max()                        # ties at the top
+        partial = rng.binomial(nS, rho)
+        rest = rng.binomial(tn - nS, rho)
+        full = partial + rest
+        if trial % 3 == 0:                                                  # make the ties exact: the same full count, split
+            top = np.flatnonzero(rho == rho.max())                          # differently between the sample and the rest
+            ft = int(full[top].min())
+            for h in top:
+                lo, hi = max(0, ft - (tn - nS)), min(nS, ft)
+                partial[h] = rng.randint(lo, hi + 1)
+                rest[h] = ft - partial[h]
+            full = partial + rest
+        lead = np.argsort(-partial, kind="stable")[:2]
+        lstar = max(int(partial[h] + rng.randint(0, rest[h] + 1)) for h in lead)      # any lower bound of a full count
+        keep = partial + (tn - nS) >= lstar
+        winners = np.flatnonzero(full == full.max())
+        assert keep[winners].all()
+        assert (partial[~keep] < full.max()).all()
+        # the arg-max over what the counters hold afterwards (full for kept, partial for dropped) is the arg-max of full
+        after = np.where(keep, full, partial)
+        assert int(np.argmax(after)) == int(np.argmax(full)) and after.max() == full.max()
