@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 #pragma unroll
             for (int q = 0; q < 2; ++q)
                 if (keep[q])
-                    f |= stage_hypothesis(sB, sCnt, base[q] + __popcll(m[q] & ((1ull << lane) - 1ull)), hp[q], org,
+                    f |= stage_hypothesis(sB, sCnt, base[q] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[q], 0u)), hp[q], org,
                                           (int)(tid + q * kBlock) << 16);
             const int pad = ((tot + 31) & ~31) - tot;
             if (tid < pad) stage_hypothesis(sB, sCnt, tot + tid, make_float2(0.f, 0.f), org, 0);

@@ -24,8 +24,9 @@
   int32 counts out) × 64 images = **1 438 777 344 B per pass** (the conservative u8-mask figure although the bench feeds
   the int64 mask `argmax` emits); `peak` = 8000 GB/s (HBM3E spec).  `traffic` = `(FETCH_SIZE + WRITE_SIZE)·1024` from
   separate `rocprofv3 --pmc` passes — a **static** figure from `profiles/count_kernel_pmc.json`, summed over the kernels of
-  the pass: {{traffic_mb}} MB (of which ≈ 100 MB is the filter instantiation's own scratch traffic — 44 B of spilled registers
-  per thread and item, §4.3 — and its counters; the compacted foreground itself is 31.5 MB, read once per launch).
+  the pass: {{traffic_mb}} MB (the compacted foreground itself is 31.5 MB, of which the first launch reads a quarter and
+  `k_lead` and the filter launch three quarters each; the rest is the counters' atomics and the filter instantiation's
+  scratch traffic — 32 B of spilled registers per thread and item, §4.3).
   **This fraction stopped discriminating in round 2 and exceeds 1 in round 3** ({{frac}}): the pass never reads the dense
   field (the mask scan and the compaction do, once) and the staged pass skips four fifths of the evaluations exactly.
   It stays in the line because the contract names it; what discriminates is reported beside it (VERDICT r2 #3):
