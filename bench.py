@@ -273,7 +273,7 @@ def main():
     # Durations of the kernels AS THEY RUN INSIDE FULL CALLS: HIP events recorded by the library at the stage boundaries of
     # `reps` calls on the launch stream (pvv_problem.ev_marks), cycling over the rotating batches exactly as the timed steps
     # do -- the same sample rocprofv3 --kernel-trace sees (VERDICT r2 #3c).  The count pass = everything between the
-    # compaction and the arg-max: one k_count_bf16 launch, or -- staged (count_prune.hpp) -- its two launches and k_prune.
+    # compaction and the arg-max: one k_count_bf16 launch, or -- staged (count_prune.hpp) -- its two launches and k_lead.
     # A second figure re-runs the count pass alone (pvv_rerun_count_kernel; a staged pass has to clear the counters first,
     # so a memset node is inside that figure).
     stage, k_avg_ms, k_med_ms, k_rerun_ms, tn_cpu, probe = None, 0.0, 0.0, 0.0, torch.zeros(0), None
@@ -364,7 +364,7 @@ def main():
         stream_gbs = probe["GBs"] if probe else None
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "kernel": ("inlier-count pass: k_count_bf16<staged> x2 + k_prune" if staged_path else "k_count_bf16"),
+                    "kernel": ("inlier-count pass: k_count_bf16<first> + k_lead + k_count_bf16<filter>" if staged_path else "k_count_bf16"),
                     "kernel_ms_avg": round(k_avg_ms, 4), "kernel_ms_median": round(k_med_ms, 4),
                     "kernel_ms_how": "HIP events recorded at the stage boundaries INSIDE full calls on the launch stream (pvv_problem.ev_marks), "
                                      "30 calls cycling over the rotating batches -- the sample rocprofv3 --kernel-trace sees",

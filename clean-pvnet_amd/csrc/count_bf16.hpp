@@ -124,7 +124,7 @@ constexpr uint32_t kStageFirst = 0x22u, kStageRest = 0xffu & ~kStageFirst;
 constexpr int kStageMinChunks = 8;
 
 struct StageArgs {
-    const int *lead;      // kCountFilter: [B,K,8] leaders' partial counts [0..3] (-1: none) and their exact counts over the
+    const int *lead;      // kCountFilter: [B,K,8] leaders' partial counts [0..3] (-1: none) and their SURE inliers among the
                           // pixels the first launch did not count [4..7] (k_lead)
     int *any_staged;      // one word: kCountFirst writes whether ANY image is staged; k_lead and kCountFilter leave at once
                           // when none is (a batch of small masks then pays two empty launches, not two table builds)
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         //      per thread (rows beyond tn are read -- the arrays reserve cap rows -- and masked below) and the
         //      hypotheses of the first group.  One memory round trip instead of three.
         const int tn_v = tn_arr[b];
-        int lead_p = -1, lead_r = 0;                            // kCountFilter: a leader's partial count and its exact rest
+        int lead_p = -1, lead_r = 0;                            // kCountFilter: a leader's partial count and its sure inliers in the rest
         if constexpr (FILTER) {
             lead_p = sa.lead[(size_t)bk * 8 + (lane & 3)];
             lead_r = sa.lead[(size_t)bk * 8 + 4 + (lane & 3)];
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             }
         }
         const int tn = __builtin_amdgcn_readfirstlane(tn_v);
-        // kCountFilter: R = pixels of the image the first launch did not count; L* = the largest exactly known full count
+        // kCountFilter: R = pixels of the image the first launch did not count; L* = the larger of the leaders' lower bounds (k_lead)
         int R_rem = 0, lstar = 0, ns_g = 0;
         if constexpr (FILTER) {
             R_rem = stage_pixels<kStageRest>(tn, (tn + PC - 1) / PC, PC);

@@ -137,11 +137,11 @@ typedef struct pvv_problem {
 #define PVV_MARK_BEGIN 0    /* before the first kernel of the call                                    */
 #define PVV_MARK_SCAN 1     /* k_tile_scan (+ k_tile_subsample)                                       */
 #define PVV_MARK_COMPACT 2  /* k_compact_hyp                                                          */
-#define PVV_MARK_COUNT 3    /* the whole inlier-count pass (every stage and k_prune when staged)      */
+#define PVV_MARK_COUNT 3    /* the whole inlier-count pass (both launches and k_lead when staged)     */
 #define PVV_MARK_SELECT 4   /* k_select_refit (v3)                                                    */
 #define PVV_MARK_END 5      /* k_finalize_v3 / k_covariance: the call is complete                     */
 #define PVV_MARK_STAGE0 6   /* staged count only: the first k_count_bf16 launch                       */
-#define PVV_MARK_PRUNE0 7   /* staged count only: the first k_prune                                   */
+#define PVV_MARK_PRUNE0 7   /* staged count only: k_lead                                                 */
 #define PVV_N_MARKS 8
 
 /* pvv_problem.count_kernel.  AUTO: the split-bf16 matrix-core prefilter with its guard band wherever it is valid
@@ -152,7 +152,8 @@ typedef struct pvv_problem {
 #define PVV_COUNT_EXACT 1
 /* ABI v6.  ransac_voting_layer_v3 keeps only the arg-max of the counts (P:160-167), so pvv_ransac_voting_v3 /
  * pvv_decode_keypoint_v3 may count in STAGES: every hypothesis over a spread quarter of the pixels, then only the
- * hypotheses that can still reach a leader's exactly known full count over the rest (k_prune).  Winner, first-index
+ * hypotheses that can still reach a lower bound of a leader's full count over the rest (k_lead, count_prune.hpp).  Winner,
+ * first-index
  * tie rule, winner count and refit are bit-identical to the full pass; what differs is that the counters of eliminated
  * hypotheses hold partial counts (they are not an output of v3).  AUTO stages when the batch is large enough for the
  * two extra launches to pay; FULL = the matrix-core kernel over everything, never staged; STAGED = staged wherever the
@@ -268,7 +269,7 @@ int pvv_stream_read_probe(const void *d_buf, size_t bytes, uint32_t *d_sink, voi
  * counters (a separate memset node) so the result stays valid; with 0 nothing
  * but the kernel is enqueued and the counters keep accumulating.  When the
  * problem counts in stages (see PVV_COUNT_STAGED) and zero_counts is 1, the
- * whole pass is re-run -- every stage and k_prune; with zero_counts = 0 the
+ * whole pass is re-run -- both launches and k_lead; with zero_counts = 0 the
  * FULL kernel runs (the elimination compares partial counts, so it needs
  * cleared counters), and an explicit PVV_COUNT_STAGED is refused then. */
 int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace,
