@@ -7,7 +7,12 @@
 
 A *step* is one ``ransac_voting_layer_v3(mask, vertex, 512, inlier_thresh=0.99)`` call through the drop-in Python API
 on a device-resident synthetic batch (free-running device RNG, exactly the call of resnet18.py:71), followed -- whenever
-a process group exists -- by the RCCL all_gather of the ``[B,K,2]`` keypoints, waited for INSIDE the step it belongs to.
+a process group exists -- by the RCCL all_gather of the ``[B,K,2]`` keypoints: enqueued asynchronously behind the step's
+voting kernels (RCCL's own stream) and waited for once the NEXT step's kernels have been launched, so the 72 B/image
+exchange runs beside them -- or completed inside its step (the launch stream waits for it), whichever a 30-step
+calibration before the timed region finds faster on this node (``--exchange auto``, the default; ``extra.exchange`` and
+``extra.exchange_calibration`` say which and why; the other variant is reported in ``extra`` for N > 1).  Either way all
+K exchanges complete inside the timed region: the last one is ordered before the closing barrier and device synchronize.
 
 Workload = BASELINE config 3: 480x640, K=9, 512 hypotheses, ~2 % foreground, 64 images.
   N = 1   the 64 images on one GPU (the configuration the roofline target is quoted on);
@@ -15,8 +20,8 @@ Workload = BASELINE config 3: 480x640, K=9, 512 hypotheses, ~2 % foreground, 64 
           batch its own network produced and the ranks exchange the keypoints: images are independent units, the path
           shards with no data-path collective.  ``--scaling strong`` is BASELINE config 3 read literally ("batch=64
           sharded over 8xMI355X"): the same 64 images in contiguous shards of 64/N (clean_pvnet_amd.dist.shard_bounds).
-          Whichever is not the headline is measured in the same run and reported in ``extra`` (with the variant that
-          overlaps the exchange of step i with the voting of step i+1); every image is generated from its global index.
+          Whichever is not the headline is measured in the same run and reported in ``extra`` (with the other exchange
+          variant); every image is generated from its global index.
 Steps cycle over --rotate (default 3) distinct device-resident batches, so that neither the 256 MiB Infinity Cache nor
 the L2 holds a step's inputs from the step before.
 
@@ -98,6 +103,13 @@ def main():
                          "mode is measured too and reported in `extra`")
     ap.add_argument("--no-weak", "--no-other-scaling", dest="no_other", action="store_true",
                     help="N > 1: skip the other scaling mode and the overlapped-exchange variant")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "overlapped", "in-step"],
+                    help="N > 1: 'overlapped' enqueues the all_gather of step i asynchronously on RCCL's stream and waits for "
+                         "it after step i+1's voting has been launched -- the collective runs beside the next step's kernels, "
+                         "every one of the K exchanges still completes inside the timed region; 'in-step' makes the launch "
+                         "stream wait for the exchange before the next step starts; 'auto' (default) times 30 steps of each "
+                         "before the timed region (max over ranks, so every rank decides alike) and takes the faster one.  The "
+                         "other one is reported in extra")
     ap.add_argument("--extras", action="store_true",
                     help="also time config 2 (B=1 latency) and v3+estimate; off by default so that a rocprofv3 "
                          "--stats run of the default command sees the count kernel at ONE problem size")
@@ -213,13 +225,46 @@ def main():
         per = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
         return elapsed, per, out
 
-    def step(i):
+    def in_step(i):
         """vote on this rank's shard of batch i, then the RCCL all_gather of the [B,K,2] keypoints -- enqueued behind the
         voting kernels and completed (stream-ordered) inside this step: nothing of step i overlaps step i+1."""
         local = vote(batches[i % len(batches)])
         return pdist.gather_results(local, global_batch) if use_dist else local
 
+    pending = []
+
+    def overlapped_step(i):
+        """the same, with the exchange enqueued asynchronously (RCCL's own stream, ordered behind this step's voting
+        kernels) and waited for only after the NEXT step's voting has been launched: the 72 B/image all_gather runs beside
+        the next step's kernels.  The last exchange is ordered before the closing barrier (same communicator) and the
+        closing device synchronize, so all K exchanges complete inside the timed region."""
+        local = vote(batches[i % len(batches)])
+        while pending:
+            pending.pop()[1].wait()
+        ow = pdist.gather_results(local, global_batch, async_op=True)
+        pending.append(ow)
+        return ow[0]
+
+    def drain():
+        while pending:
+            pending.pop()[1].wait()
+
+    calibration = None
+    if use_dist and args.exchange == "auto":
+        # which way of exchanging is faster depends on the node (collective latency vs what a concurrent RCCL kernel costs
+        # the voting kernels): decide by measurement, before the timed region; `run` returns the max over ranks, which is
+        # the same number on every rank
+        c_in, _p, _o = run(in_step, 3, 30)
+        c_ov, _p, _o = run(overlapped_step, 3, 30)
+        drain()
+        calibration = {"in_step_ms_per_step": round(1e3 * c_in / 30, 4), "overlapped_ms_per_step": round(1e3 * c_ov / 30, 4)}
+        overlapped = c_ov < c_in
+    else:
+        overlapped = use_dist and args.exchange == "overlapped"
+    step = overlapped_step if overlapped else in_step
+
     elapsed, per_step, out = run(step, args.warmup, args.steps)
+    drain()
     ms_per_step = 1e3 * elapsed / args.steps
     value = global_batch * args.steps / elapsed
     last = batches[(args.warmup + args.steps - 1) % len(batches)]
@@ -252,22 +297,13 @@ def main():
             return pdist.gather_results(vote(ob[i % 2]), o_global)
         n2 = max(10, args.steps // 4)
         w_el, w_per, _ = run(other_step, 5, n2)
-        pending = []
-        def overlapped_step(i):
-            local = vote(batches[i % len(batches)])
-            while pending:
-                pending.pop()[1].wait()
-            ow = pdist.gather_results(local, global_batch, async_op=True)
-            pending.append(ow)
-            return ow[0]
-        o_el, o_per, _ = run(overlapped_step, 5, n2)
-        while pending:
-            pending.pop()[1].wait()
+        x_el, x_per, _ = run(in_step if overlapped else overlapped_step, 5, n2)
+        drain()
         oname = "strong" if weak else "weak"
         other = {"%s_scaling_images_per_s" % oname: round(o_global * n2 / w_el, 1),
                  "%s_scaling_ms_per_step" % oname: round(1e3 * w_el / n2, 4),
                  "%s_scaling_global_batch" % oname: o_global, "%s_scaling_images_per_gpu" % oname: ohi - olo,
-                 "overlapped_exchange_images_per_s": round(global_batch * n2 / o_el, 1)}
+                 ("in_step_exchange_images_per_s" if overlapped else "overlapped_exchange_images_per_s"): round(global_batch * n2 / x_el, 1)}
         del ob
 
     # Durations of the kernels AS THEY RUN INSIDE FULL CALLS: HIP events recorded by the library at the stage boundaries of
@@ -430,7 +466,11 @@ def main():
                  "collective_ranks": coll_ranks, "rccl_ranks": (coll_ranks if backend == "nccl" else None),
                  "per_rank_count_kernel_ms": per_rank_kernel_ms,
                  "kernels_inside_calls_ms": stage, "stream_read_probe": probe, "count_pass_staged": staged_path,
-                 "exchange": ("all_gather_into_tensor of [%d,%d,2] f32 inside every step" % (global_batch, K)) if use_dist else None}
+                 "exchange": (("all_gather_into_tensor of [%d,%d,2] f32 per step, " % (global_batch, K)) +
+                              ("enqueued asynchronously behind the step's voting kernels and waited for after the next step's "
+                               "launches (it runs beside them); all K complete before the closing barrier + synchronize"
+                               if overlapped else "completed inside the step (the launch stream waits for it)")) if use_dist else None,
+                 "exchange_calibration": calibration}
         if world > 1:
             extra["scaling_vs_n1_profile"] = predict_from_profile(args.config, global_batch, world, max(shard_sizes), value, weak)
         if other:
@@ -453,7 +493,7 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 3 (%s): %dx%d, K=%d, %d hypotheses, ~%.0f%% foreground, int64 mask, contiguous "
                                    "[B,H,W,K,2] f32 vertex; global batch %d in contiguous shards of %d images per GPU; "
-                                   "ransac_voting_layer_v3 (+ RCCL all_gather of [B,K,2] inside the step for N>1); steps "
+                                   "ransac_voting_layer_v3 (+ one RCCL all_gather of [B,K,2] per step for N>1, see extra.exchange); steps "
                                    "cycle over %d distinct device-resident batches"
                                    % (args.config, H, W, K, hn, 100 * (cfg["fg"] if not isinstance(cfg["fg"], tuple) else cfg["fg"][1]),
                                       global_batch, B, len(batches)),

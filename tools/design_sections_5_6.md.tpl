@@ -1,8 +1,8 @@
 ## 5. Measurement (bench.py)
 
 * Step = one `ransac_voting_layer_v3(mask, vertex, 512, inlier_thresh=0.99)` through the drop-in Python API,
-  device-resident synthetic batch, device RNG, + (whenever a process group exists) the RCCL `all_gather` of `[B,K,2]`,
-  completed inside the step it belongs to.  Workload = BASELINE config 3, **64 images per GPU**: N = 1 is the
+  device-resident synthetic batch, device RNG, + (whenever a process group exists) the RCCL `all_gather` of `[B,K,2]`
+  (completed inside its step, or overlapped with the next step's voting: §6).  Workload = BASELINE config 3, **64 images per GPU**: N = 1 is the
   configuration the roofline target is quoted on; N > 1 — see §6.  `--extras` adds config 2 (B = 1 latency), v3 +
   estimate, the default path, `decode_keypoint`.
 * Protocol (SURVEY §8(d), VERDICT r1 #3): steps cycle over **3 distinct device-resident batches** (4.7 GB: neither the
@@ -93,16 +93,27 @@ the common key and `first_image` = the index of its first image, so the device-R
 every number of GPUs. The reference has no counterpart (its only multi-GPU mechanism is `nn.DataParallel` for training).
 
 **What `bench.py --gpus N` measures.**  `"scaling": "weak"` (default): 64 images PER GPU, global batch 64·N — every rank
-decodes the batch its own network produced and the ranks exchange the keypoints inside the step; this is how the path is
+decodes the batch its own network produced and the ranks exchange the keypoints once per step; this is how the path is
 deployed (data-parallel inference), and it is what the rule for a path that shards prescribes (no data-path collective,
 weak scaling).  The exchange is the only addition to a step, so the expectation is near-linear: N × the one-GPU figure
 minus the 10–30 µs `all_gather` per {{ms}} ms step.  `--scaling strong` is BASELINE config 3 read literally ("batch=64 sharded
 over 8×MI355X"): the same 64 images in shards of 64/N.  Rounds 1–2 reported that as the headline; its limit is the
 latency floor of a small shard, not the exchange: 64 images take {{ms}} ms on one GPU, a shard of 8 takes 0.065 ms (+ the
 exchange) ⇒ ≈ 2.5–3× on 8 GPUs.  Whichever mode is not the headline is measured in the same run and reported in `extra`
-(`strong_scaling_images_per_s` / `weak_scaling_images_per_s`), with the variant that overlaps the exchange of step i with
-the voting of step i+1, per-rank shard sizes, per-rank count-pass times, `collective_ranks` / `rccl_ranks` and
+(`strong_scaling_images_per_s` / `weak_scaling_images_per_s`), with the other exchange variant, per-rank shard sizes, per-rank count-pass times, `collective_ranks` / `rccl_ranks` and
 `scaling_vs_n1_profile` (what `profiles/r02_configs.json` predicts for this N and shard size, and measured ÷ predicted).
+
+**The exchange, two ways** (`--exchange auto|in-step|overlapped`).  *In-step*: `all_gather_into_tensor` with the launch
+stream waiting for it before the next step's kernels — nothing of step i overlaps step i+1.  *Overlapped*: the collective
+is enqueued asynchronously (RCCL's own stream, ordered behind the step's voting kernels) and waited for only after the
+NEXT step's kernels have been launched, so it runs beside them; the last one is ordered before the closing barrier, so all K
+exchanges still complete inside the timed region.  Which is faster depends on the node — the collective's latency against
+what a concurrent RCCL kernel and two more cross-stream events cost the voting kernels: with the ONE-rank RCCL group the
+test box offers, in-step costs 12–15 µs per step and overlapped 30 µs (`tools/timeline.py` on a kernel trace: the device
+idles 15 / 32 µs per step; `tools/coll_host.py`: the async path also costs the host 33 instead of 15 µs per collective).  So
+`auto` (the default) times 30 steps of each before the timed region — max over ranks, so every rank decides alike — and
+takes the faster; `extra.exchange` / `extra.exchange_calibration` say which and why, and the other variant's rate is in
+`extra` as well.
 
 **Plumbing** (VERDICT r2 #1).  `python bench.py --gpus N` launched BARE (no `WORLD_SIZE`) starts its N ranks itself under
 `torch.distributed.run` (rendezvous on 127.0.0.1) instead of dying on an assertion; under the driver's own
