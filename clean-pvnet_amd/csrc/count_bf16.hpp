@@ -119,8 +119,12 @@ enum { kCountFull = 0, kCountFirst = 1, kCountFilter = 2 };
 // parameters they were a dozen integer divisions per work item): the first launch counts the 512-pixel chunks c with
 // (c mod 8) in {1, 5} -- a quarter of the chunks, spread over the object (rows of the compacted list = raster order) --,
 // the second launch the other residues; images of fewer than kStageMinChunks chunks are counted completely by the first.
-constexpr int kStageM = 8;
-constexpr uint32_t kStageFirst = 0x22u, kStageRest = 0xffu & ~kStageFirst;
+#ifndef PVV_STAGE_M                    // (tools/build_variant.sh -DPVV_STAGE_M=.. -DPVV_STAGE_FIRST=..: schedule sweeps)
+#define PVV_STAGE_M 8
+#define PVV_STAGE_FIRST 0x22u
+#endif
+constexpr int kStageM = PVV_STAGE_M;
+constexpr uint32_t kStageFirst = PVV_STAGE_FIRST, kStageRest = ((1u << kStageM) - 1u) & ~kStageFirst;
 constexpr int kStageMinChunks = 8;
 
 struct StageArgs {
