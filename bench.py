@@ -559,6 +559,18 @@ def extras_leg(extra, data, out, ext, synth, ransac_voting_layer_v3, estimate_vo
         ransac_voting_layer_v3(m1, v1, hn, inlier_thresh=thresh)
     torch.cuda.synchronize()
     extra["cfg2_B1_ms_per_image"] = round(1e3 * (time.perf_counter() - t1) / n1, 4)
+    # the same 64-image call with the mask as uint8 (1 B/pixel -- SURVEY 8d's algorithmic figure -- instead of the int64
+    # torch.argmax emits, which is what the headline feeds): what a caller who can choose the mask's dtype gets
+    m8 = mask.to(torch.uint8)
+    for _ in range(10):
+        ransac_voting_layer_v3(m8, vertex, hn, inlier_thresh=thresh)
+    torch.cuda.synchronize()
+    t8 = time.perf_counter()
+    for _ in range(50):
+        ransac_voting_layer_v3(m8, vertex, hn, inlier_thresh=thresh)
+    torch.cuda.synchronize()
+    extra["uint8_mask_images_per_s_one_batch_replayed"] = round(B * 50 / (time.perf_counter() - t8), 1)
+    del m8
     # the un_pnp path of resnet18.py:71-72: v3 + estimate (4096 hypotheses)
     for _ in range(2):
         estimate_voting_distribution_with_mean(mask, vertex, out)

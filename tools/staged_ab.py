@@ -32,6 +32,10 @@ def main():
     ap.add_argument("--cases", default="cfg3:8,cfg3:16,cfg3:32,cfg3:64,cfg4:32,cfg5:16")
     ap.add_argument("--calls", type=int, default=60)
     ap.add_argument("--rotate", type=int, default=2)
+    ap.add_argument("--outlier", type=float, default=None,
+                    help="override the configs' outlier fraction: pixels whose direction is random (a winner then explains "
+                         "fewer pixels and the elimination bites later or not at all)")
+    ap.add_argument("--sigma", type=float, default=None, help="override the configs' direction noise")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -42,8 +46,12 @@ def main():
         cfg = dict(synth.CONFIGS[cfgname])
         hn, K = cfg["hn"], cfg["K"]
         gen = {k: v for k, v in cfg.items() if k not in ("B", "hn")}
+        if args.outlier is not None:
+            gen["outlier"] = args.outlier
+        if args.sigma is not None:
+            gen["sigma"] = args.sigma
         batches = [synth.make_batch(B=B, **gen, first_index=1000 * r, device=dev) for r in range(args.rotate)]
-        row = {"case": case, "hn": hn, "K": K}
+        row = {"case": case, "hn": hn, "K": K, "outlier": gen.get("outlier", 0.0), "sigma": gen.get("sigma")}
         outs = {}
         for name, mode in (("full", ext.COUNT_FULL), ("staged", ext.COUNT_STAGED), ("auto", ext.COUNT_AUTO)):
             def call(i):
