@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "pvnet_vote.h"
 
@@ -74,6 +75,7 @@ struct Layout {
     int T;
     size_t tiles, tile_list, tile_draw, tn, surv, coords, dirs, hyps, counts, sums, total;
     size_t lead;                                     // staged counting (count_prune.hpp): [B,K,8] leader counts; 0 = not reserved
+    size_t ratio;                                    // [B,K] winner count / tn (k_select_refit -> k_finalize_v3 -> stage hint)
 };
 
 bool use_bf16_count(const pvv_problem *p);
@@ -96,6 +98,7 @@ Layout make_layout(const pvv_problem *p)
     L.hyps = take(sizeof(float2) * (size_t)p->B * p->K * p->hn);
     L.counts = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
     L.sums = take(sizeof(double) * (size_t)p->B * p->K * kRefitSplitMax * 5);
+    L.ratio = take(sizeof(float) * (size_t)p->B * p->K);
     L.lead = may_stage(p) ? take(sizeof(int) * ((size_t)p->B * p->K * 8 + 1)) : 0;   // + the any_staged word
     L.total = off;
     return L;
@@ -180,6 +183,77 @@ bool may_stage(const pvv_problem *p)
     // call, max_num = 100: 244 rows)
     return p->hn >= 128 && p->cap >= kStageMinChunks * 4 * kBfPixPerWave &&
            (double)p->B * p->K * p->hn * p->H * p->W >= kStageMinWork;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The stage hint.  Whether staged counting pays depends on how clean the vector field is -- on the winners' inlier ratio
+// rho, which the host cannot know before the call: measured on MI355X (tools/staged_ab.py --outlier ..),
+// 480x640, K = 9, 512 hypotheses at B = 64: +26 % at rho = 0.995, +5 % at 0.95, +-0 at 0.90, -4 % at 0.80 (a quarter of
+// the pixels then eliminates nothing and the call pays for the two extra launches); at B = 16 the break-even is rho ~
+// 0.97; 540x720, K = 17, 2048 hypotheses gains down to rho = 0.8 and below.  But consecutive calls see similar data (a
+// video, a dataset, one network), and every call -- staged or not -- ends with the exact winner counts.  So
+// k_finalize_v3 leaves each image's mean winner ratio in a small host-visible array (one per device, pinned, written by
+// the GPU with plain stores), and AUTO stages a call only if the ratios the LAST completed calls left there reach a
+// threshold that depends on the problem's size.  The hint lags by the calls still in flight and mixes calls when several
+// streams or problem shapes interleave; it only ever selects between two exact paths.  No data yet (first call, or first
+// call under stream capture, where no memory can be pinned): stage.  PVV_COUNT_STAGED / PVV_COUNT_FULL ignore it.
+// ---------------------------------------------------------------------------------------------
+struct StageHint {
+    float *ratio = nullptr;   // kMaxBatchLds floats, hipHostMalloc: < -1.5 = never written, -1 = skipped image
+    int n = 0;                // images of the last call that was given the buffer
+    bool tried = false;
+};
+StageHint g_hint[64];
+std::mutex g_hint_mu;
+
+StageHint *stage_hint(hipStream_t st, bool allocate)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    StageHint *g = &g_hint[dev];
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    if (!g->tried && allocate) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (cs != hipStreamCaptureStatusNone) return nullptr;            // pinning memory is not allowed while capturing
+        g->tried = true;
+        void *q = nullptr;
+        if (hipHostMalloc(&q, sizeof(float) * kMaxBatchLds, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
+        g->ratio = (float *)q;
+        if (g->ratio) for (int i = 0; i < kMaxBatchLds; ++i) g->ratio[i] = -2.f;
+    }
+    return g->ratio ? g : nullptr;
+}
+
+// mean winner ratio of the images the last calls reported; < 0: no data
+float stage_hint_mean(hipStream_t st)
+{
+    StageHint *g = stage_hint(st, false);
+    if (!g || g->n <= 0) return -1.f;
+    double sum = 0;
+    int cnt = 0;
+    const volatile float *r = g->ratio;
+    for (int i = 0; i < g->n; ++i) {
+        const float v = r[i];
+        if (v < -1.5f) return -1.f;                                       // an image of the last call has not reported yet
+        if (v >= 0.f) { sum += v; ++cnt; }
+    }
+    return cnt ? (float)(sum / cnt) : -1.f;
+}
+
+// the break-even ratio from the measurements above: lower for more work per call and for more hypotheses per keypoint
+float stage_hint_threshold(const pvv_problem *p)
+{
+    const double work = (double)p->B * p->K * p->hn * p->H * p->W;
+    double thr = 0.976 - 0.035 * std::log2(work / 2.26e10) - 0.1 * std::log2(std::max(p->hn, 512) / 512.0);
+    return (float)std::min(0.985, std::max(0.5, thr));
+}
+
+bool stage_hint_allows(const pvv_problem *p, hipStream_t st)
+{
+    if (p->count_kernel != PVV_COUNT_AUTO) return true;
+    const float m = stage_hint_mean(st);
+    return m < 0.f || m >= stage_hint_threshold(p);
 }
 
 Bf16Consts bf16_consts(float thresh)
@@ -332,7 +406,7 @@ int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_
 {
     if (p->ev_count_begin && hipEventRecord((hipEvent_t)p->ev_count_begin, st) != hipSuccess)
         return fail(PVV_E_ARG, "ev_count_begin is not a valid hipEvent_t");
-    const bool staged = v3 && may_stage(p) && L.lead != 0;
+    const bool staged = v3 && may_stage(p) && L.lead != 0 && stage_hint_allows(p, st);
     const int e = use_bf16_count(p) ? launch_count_bf16(p, L, ws, st, staged) : launch_count(planar_count_args(p, L, ws), st);
     if (e) return e;
     if (p->ev_count_end && hipEventRecord((hipEvent_t)p->ev_count_end, st) != hipSuccess)
@@ -485,6 +559,14 @@ int check_ptrs(const pvv_problem *p, const void *mask, const void *vertex, void 
 PVV_EXPORT int pvv_abi_version(void) { return PVV_ABI_VERSION; }
 PVV_EXPORT const char *pvv_last_error(void) { return g_err; }
 
+PVV_EXPORT int pvv_stage_hint_query(float *mean_ratio, float *threshold, const pvv_problem *p, void *stream)
+{
+    const float m = stage_hint_mean((hipStream_t)stream);
+    if (mean_ratio) *mean_ratio = m;
+    if (threshold) *threshold = p ? stage_hint_threshold(p) : -1.f;
+    return m >= 0.f ? 1 : 0;
+}
+
 PVV_EXPORT int32_t pvv_default_cap(int32_t H, int32_t W, int32_t max_num)
 {
     long long hw = (long long)H * W;
@@ -513,11 +595,14 @@ static int finish_v3(const pvv_problem *p, const Layout &L, char *ws, float *d_o
                        (const int *)(ws + L.tn), (const float2 *)(ws + L.coords),
                        (const float2 *)(ws + L.dirs), (const float2 *)(ws + L.hyps),
                        (const int *)(ws + L.counts), (double *)(ws + L.sums), d_win_counts, p->K, p->hn, hstride,
-                       p->cap, p->inlier_thresh, nsplit);
+                       p->cap, p->inlier_thresh, nsplit, (float *)(ws + L.ratio));
     if (int e = check_launch("k_select_refit")) return e;
     if (int e = mark(p, PVV_MARK_SELECT, st)) return e;
+    StageHint *hint = stage_hint(st, true);
+    if (hint) hint->n = p->B;
     hipLaunchKernelGGL(k_finalize_v3, dim3(p->B), dim3(64), 0, st, (const int *)(ws + L.tn),
-                       (const double *)(ws + L.sums), (float2 *)d_out, p->K, p->singular_policy, nsplit);
+                       (const double *)(ws + L.sums), (float2 *)d_out, p->K, p->singular_policy, nsplit,
+                       (const float *)(ws + L.ratio), hint ? hint->ratio : nullptr);
     if (int e = check_launch("k_finalize_v3")) return e;
     return mark(p, PVV_MARK_END, st);
 }

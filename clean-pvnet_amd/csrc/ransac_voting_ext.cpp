@@ -550,6 +550,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           "per-stage durations inside full v3 calls, HIP events at the stage boundaries (profiling aid)", py::arg("masks"),
           py::arg("vertices"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"),
           py::arg("seed"), py::arg("reps"), py::arg("count_kernel") = 0, py::arg("inner_marks") = true, py::arg("estimate") = false);
+    m.def("stage_hint", [](at::Tensor mask, at::Tensor vertex, int64_t hn) {
+              pvv_problem p = make_problem(mask, vertex, hn, 0.99, 5, 30000, 0, 0);
+              float mean = -1.f, thr = -1.f;
+              const int valid = pvv_stage_hint_query(&mean, &thr, &p, cur_stream(vertex));
+              return std::make_tuple(valid != 0, (double)mean, (double)thr);
+          }, "pvv_stage_hint_query for this problem shape -> (data there, mean winner ratio of the last calls, AUTO's threshold)",
+          py::arg("mask"), py::arg("vertex"), py::arg("hn"));
     m.def("stream_read_probe", &stream_read_probe, "one read-once streaming pass over a buffer (bench aid)");
     m.def("count_kernel_ms_in_pipeline", &count_kernel_ms_in_pipeline,
           "duration of the inlier-count kernel inside full v3 calls, HIP events around its launch (profiling aid)",

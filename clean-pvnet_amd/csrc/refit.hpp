@@ -20,7 +20,7 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
     const float2 *__restrict__ dirs, const float2 *__restrict__ hyps,
     const int *__restrict__ counts, double *__restrict__ sums /*[B,K,nsplit,5]*/,
     int *__restrict__ win_counts /*[B,K] or null*/, int K, int hn, int hstride /*row length of hyps / counts (>= hn)*/,
-    int cap, float thresh, int nsplit)
+    int cap, float thresh, int nsplit, float *__restrict__ win_ratio /*[B,K]: winner count / tn (k_finalize_v3's stage hint)*/)
 {
     __shared__ int s_cnt[4], s_idx[4];
     __shared__ double red5[20];
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
         if (threadIdx.x == 0) {
             for (int i = 0; i < 5; ++i) part[i] = 0.0;
             if (win_counts && split == 0) win_counts[bk] = 0;
+            if (split == 0) win_ratio[bk] = -1.f;
         }
         return;
     }
@@ -95,19 +96,32 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
     }
     __syncthreads();
     if (threadIdx.x < 5) part[threadIdx.x] = red5[threadIdx.x] + red5[5 + threadIdx.x] + red5[10 + threadIdx.x] + red5[15 + threadIdx.x];
-    if (threadIdx.x == 0 && win_counts && split == 0) win_counts[bk] = best;
+    if (threadIdx.x == 0 && split == 0) {
+        if (win_counts) win_counts[bk] = best;
+        win_ratio[bk] = (float)best / (float)tn;
+    }
 }
 
 // Merge the partial normal equations, solve the 2x2 systems (P:193, closed form in binary64) and apply the
 // singular-matrix policy across the keypoints of an image (b_inv, P:97-109).  One block per image.
+// Also reports the image's mean winner ratio (winner count / tn over its keypoints; -1: image skipped) to hint[b] --
+// host-visible memory the NEXT calls read to decide whether staged counting pays (stage_hint_allows, pvnet_vote.hip);
+// hint may be null.
 __global__ __launch_bounds__(64) void k_finalize_v3(const int *__restrict__ tn_arr, const double *__restrict__ sums,
-                                                    float2 *__restrict__ out, int K, int policy, int nsplit)
+                                                    float2 *__restrict__ out, int K, int policy, int nsplit,
+                                                    const float *__restrict__ win_ratio, float *hint)
 {
     __shared__ int any_singular;
     const int b = blockIdx.x;
     if (threadIdx.x == 0) any_singular = 0;
     __syncthreads();
     const bool skipped = tn_arr[b] <= 0;
+    if (hint) {
+        float r = 0.f;
+        for (int vi = threadIdx.x; vi < K; vi += 64) r += win_ratio[(size_t)b * K + vi];
+        r = wave_sum(r);
+        if (threadIdx.x == 0) hint[b] = skipped ? -1.f : r / (float)K;
+    }
     for (int v0 = 0; v0 < K; v0 += 64) {          // K <= 64 in every real use: one trip
         const int vi = v0 + threadIdx.x;
         float2 o = make_float2(0.f, 0.f);

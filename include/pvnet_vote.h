@@ -263,6 +263,16 @@ int pvv_decode_keypoint_un_pnp(const pvv_problem *p, int32_t hn_est, const float
  * d_sink (so the loads cannot be elided); bracket it with events on `stream`.  Nothing of the voting path uses it. */
 int pvv_stream_read_probe(const void *d_buf, size_t bytes, uint32_t *d_sink, void *stream);
 
+/* The stage hint (ABI v6).  Whether staged counting pays depends on how clean the vector field is -- on the winners'
+ * inlier ratio, which nobody knows before the call -- but consecutive calls see similar data, and every v3 call ends with
+ * the exact winner counts.  The library therefore keeps, per device, the mean winner ratio (winner count / tn) of every
+ * image of the last completed v3 calls in a small pinned array the GPU writes, and PVV_COUNT_AUTO stages a call only if
+ * that mean reaches a threshold that depends on the problem's size (pvnet_vote.hip, stage_hint_threshold; DESIGN.md
+ * 4.6).  The hint lags by the calls in flight and only selects between two exact paths; with no data yet the call is
+ * staged; PVV_COUNT_STAGED / PVV_COUNT_FULL ignore it.  This query is for tests, benches and the curious: returns 1 and
+ * the mean when data is there (0 and -1 otherwise), and the threshold of `p` (p may be NULL: -1). */
+int pvv_stage_hint_query(float *mean_ratio, float *threshold, const pvv_problem *p, void *stream);
+
 /* Bench / profiling aid: re-runs ONLY the inlier-count kernel of the last
  * layer call recorded in `d_workspace` (same problem), so its duration can be
  * bracketed with HIP events on `stream`.  zero_counts != 0 first clears the

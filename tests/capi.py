@@ -55,6 +55,7 @@ def load():
                                                        vp, vp, vp, vp, vp, vp]
         L.pvv_rerun_count_kernel.argtypes = [ctypes.POINTER(Problem), vp, sz, ctypes.c_int, vp]
         L.pvv_stream_read_probe.argtypes = [vp, sz, vp, vp]
+        L.pvv_stage_hint_query.argtypes = [ctypes.POINTER(c_f32), ctypes.POINTER(c_f32), ctypes.POINTER(Problem), vp]
         _lib = L
     return _lib
 

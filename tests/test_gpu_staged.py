@@ -291,3 +291,34 @@ def test_stage_marks_and_stream_probe(synth, pkg, gpu):
         _o, _w, _t, ws = ext.ransac_voting_v3(d["mask"], d["vertex"], 512, 0.99, 5, 30000, None, None, 1, ext.SINGULAR_REFERENCE,
                                               count_kernel=ext.COUNT_STAGED)
         ext.rerun_count_kernel(d["mask"], d["vertex"], 512, 0.99, 5, 30000, ws, False, ext.COUNT_STAGED)
+
+
+def test_auto_follows_the_stage_hint(synth, pkg, gpu):
+    """PVV_COUNT_AUTO stages a v3 call only if the winner ratios the last completed calls left in the per-device hint
+    reach the problem's threshold (pvv_stage_hint_query): after calls on a clean field the next calls are staged, after
+    calls on a field with 35 % outlier pixels they are not -- and either way the results are those of the full pass."""
+    from clean_pvnet_amd import ransac_voting as ext
+    c = {**synth.CONFIGS["cfg3"], "B": 16}                        # 2.3e10: large enough for AUTO to consider staging
+    hn = c["hn"]
+    clean = synth.make_batch(**c, seed=21, device=gpu)
+    noisy = synth.make_batch(**{**c, "outlier": 0.35}, seed=22, device=gpu)
+
+    def v3(d, k):
+        return ext.ransac_voting_v3(d["mask"], d["vertex"], hn, 0.99, 5, 30000, None, None, 5, ext.SINGULAR_REFERENCE, count_kernel=k)
+
+    for d, want_staged in ((clean, True), (noisy, False), (clean, True)):
+        for _ in range(3):
+            out, win, tn, _ws = v3(d, ext.COUNT_AUTO)
+        torch.cuda.synchronize()
+        valid, mean, thr = ext.stage_hint(d["mask"], d["vertex"], hn)
+        ratio = float((win.double() / tn.double().view(-1, 1)).mean())
+        assert valid and abs(mean - ratio) < 1e-4, (mean, ratio)
+        assert 0.5 <= thr <= 0.985 and (mean >= thr) == want_staged, (mean, thr)
+        ms = ext.stage_ms_in_pipeline([d["mask"]], [d["vertex"]], hn, 0.99, 5, 30000, 5, 3, ext.COUNT_AUTO)
+        assert all((r[5] > 0) == want_staged for r in ms), ms     # the first count launch's mark: recorded iff staged
+        ref = v3(d, ext.COUNT_FULL)
+        got = v3(d, ext.COUNT_AUTO)
+        assert all(torch.equal(a, b) for a, b in zip(got[:3], ref[:3]))
+        # the explicit modes ignore the hint
+        assert all(r[5] > 0 for r in ext.stage_ms_in_pipeline([d["mask"]], [d["vertex"]], hn, 0.99, 5, 30000, 5, 2, ext.COUNT_STAGED))
+        assert all(r[5] < 0 for r in ext.stage_ms_in_pipeline([d["mask"]], [d["vertex"]], hn, 0.99, 5, 30000, 5, 2, ext.COUNT_FULL))

@@ -81,6 +81,8 @@ def main():
             cols = ("scan", "compact", "count_pass", "select", "finalize", "stage0", "prune")
             row[name] = {"ms_per_call": round(ms, 4), "images_per_s": round(B / ms * 1e3, 1),
                          **{c: round(med([r[j] for r in st]), 4) for j, c in enumerate(cols) if med([r[j] for r in st]) >= 0}}
+        win, tn = outs["full"][1].double(), outs["full"][2].double()
+        row["mean_winner_ratio"] = round(float((win / tn.clamp(min=1).view(-1, 1)).mean()), 4)
         row["staged_equals_full"] = all(torch.equal(a, b) for a, b in zip(outs["full"], outs["staged"]))
         row["speedup_call"] = round(row["full"]["ms_per_call"] / row["staged"]["ms_per_call"], 3)
         row["speedup_count_pass"] = round(row["full"]["count_pass"] / row["staged"]["count_pass"], 3)
