@@ -199,7 +199,8 @@ bool may_stage(const pvv_problem *p)
 // call under stream capture, where no memory can be pinned): stage.  PVV_COUNT_STAGED / PVV_COUNT_FULL ignore it.
 // ---------------------------------------------------------------------------------------------
 struct StageHint {
-    float *ratio = nullptr;   // kMaxBatchLds floats, hipHostMalloc: < -1.5 = never written, -1 = skipped image
+    float *ratio = nullptr;   // 2 x kMaxBatchLds floats, hipHostMalloc: [b] winner ratio (< -1.5 = never written, -1 = skipped
+                              // image), [kMaxBatchLds + b] the image's tn
     int n = 0;                // images of the last call that was given the buffer
     bool tried = false;
 };
@@ -218,26 +219,30 @@ StageHint *stage_hint(hipStream_t st, bool allocate)
         if (cs != hipStreamCaptureStatusNone) return nullptr;            // pinning memory is not allowed while capturing
         g->tried = true;
         void *q = nullptr;
-        if (hipHostMalloc(&q, sizeof(float) * kMaxBatchLds, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
+        if (hipHostMalloc(&q, sizeof(float) * 2 * kMaxBatchLds, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
         g->ratio = (float *)q;
-        if (g->ratio) for (int i = 0; i < kMaxBatchLds; ++i) g->ratio[i] = -2.f;
+        if (g->ratio) for (int i = 0; i < 2 * kMaxBatchLds; ++i) g->ratio[i] = -2.f;
     }
     return g->ratio ? g : nullptr;
 }
 
-// mean winner ratio of the images the last calls reported; < 0: no data
-float stage_hint_mean(hipStream_t st)
+// mean winner ratio of the images the last calls reported (< 0: no data) and the largest tn among them
+float stage_hint_mean(hipStream_t st, float *max_tn = nullptr)
 {
     StageHint *g = stage_hint(st, false);
+    if (max_tn) *max_tn = -1.f;
     if (!g || g->n <= 0) return -1.f;
     double sum = 0;
     int cnt = 0;
+    float mt = 0.f;
     const volatile float *r = g->ratio;
     for (int i = 0; i < g->n; ++i) {
         const float v = r[i];
         if (v < -1.5f) return -1.f;                                       // an image of the last call has not reported yet
         if (v >= 0.f) { sum += v; ++cnt; }
+        mt = std::max(mt, (float)r[kMaxBatchLds + i]);
     }
+    if (max_tn) *max_tn = mt;
     return cnt ? (float)(sum / cnt) : -1.f;
 }
 
@@ -252,8 +257,12 @@ float stage_hint_threshold(const pvv_problem *p)
 bool stage_hint_allows(const pvv_problem *p, hipStream_t st)
 {
     if (p->count_kernel != PVV_COUNT_AUTO) return true;
-    const float m = stage_hint_mean(st);
-    return m < 0.f || m >= stage_hint_threshold(p);
+    float max_tn = -1.f;
+    const float m = stage_hint_mean(st, &max_tn);
+    if (m < 0.f) return true;
+    // (images of fewer than kStageMinChunks chunks are counted completely by the first launch: when the last calls held
+    // no larger one -- config 4's sparse masks -- the two later launches would only be launched to leave again)
+    return m >= stage_hint_threshold(p) && max_tn > (float)((kStageMinChunks - 1) * 4 * kBfPixPerWave);
 }
 
 Bf16Consts bf16_consts(float thresh)
@@ -602,7 +611,7 @@ static int finish_v3(const pvv_problem *p, const Layout &L, char *ws, float *d_o
     if (hint) hint->n = p->B;
     hipLaunchKernelGGL(k_finalize_v3, dim3(p->B), dim3(64), 0, st, (const int *)(ws + L.tn),
                        (const double *)(ws + L.sums), (float2 *)d_out, p->K, p->singular_policy, nsplit,
-                       (const float *)(ws + L.ratio), hint ? hint->ratio : nullptr);
+                       (const float *)(ws + L.ratio), hint ? hint->ratio : nullptr, kMaxBatchLds);
     if (int e = check_launch("k_finalize_v3")) return e;
     return mark(p, PVV_MARK_END, st);
 }

@@ -104,12 +104,12 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
 
 // Merge the partial normal equations, solve the 2x2 systems (P:193, closed form in binary64) and apply the
 // singular-matrix policy across the keypoints of an image (b_inv, P:97-109).  One block per image.
-// Also reports the image's mean winner ratio (winner count / tn over its keypoints; -1: image skipped) to hint[b] --
-// host-visible memory the NEXT calls read to decide whether staged counting pays (stage_hint_allows, pvnet_vote.hip);
+// Also reports the image's mean winner ratio (winner count / tn over its keypoints; -1: image skipped) to hint[b] and its
+// tn to hint[hint_stride + b] -- host-visible memory the NEXT calls read to decide whether staged counting pays (stage_hint_allows, pvnet_vote.hip);
 // hint may be null.
 __global__ __launch_bounds__(64) void k_finalize_v3(const int *__restrict__ tn_arr, const double *__restrict__ sums,
                                                     float2 *__restrict__ out, int K, int policy, int nsplit,
-                                                    const float *__restrict__ win_ratio, float *hint)
+                                                    const float *__restrict__ win_ratio, float *hint, int hint_stride)
 {
     __shared__ int any_singular;
     const int b = blockIdx.x;
@@ -120,7 +120,10 @@ __global__ __launch_bounds__(64) void k_finalize_v3(const int *__restrict__ tn_a
         float r = 0.f;
         for (int vi = threadIdx.x; vi < K; vi += 64) r += win_ratio[(size_t)b * K + vi];
         r = wave_sum(r);
-        if (threadIdx.x == 0) hint[b] = skipped ? -1.f : r / (float)K;
+        if (threadIdx.x == 0) {
+            hint[b] = skipped ? -1.f : r / (float)K;
+            hint[hint_stride + b] = (float)tn_arr[b];              // (the host also learns whether any image is large enough to stage)
+        }
     }
     for (int v0 = 0; v0 < K; v0 += 64) {          // K <= 64 in every real use: one trip
         const int vi = v0 + threadIdx.x;

@@ -21,7 +21,7 @@ table = '\n'.join([
  "  " + row('cfg3_B16', '3: same, B=16'),
  "  " + row('cfg3_B32', '3: same, B=32', ' (round 2: 0.1533 ms)'),
  "  " + row('cfg3_B64', '3: same, **B=64** (one batch replayed: warm caches)', ' (round 2: 0.2612 ms, count kernel 0.1901)'),
- "  " + row('cfg4_B32', '4: sparse/occluded (tn≈1.5 k), 1024 hyp, B=32', ' (round 2: 0.1016 ms; nothing to stage, see below)'),
+ "  " + row('cfg4_B32', '4: sparse/occluded (tn≈1.5 k), 1024 hyp, B=32', ' (round 2: 0.1016 ms)'),
  "  " + row('cfg4_B4_shard_of_8gpu', '4: same, B=4 (shard of 8 GPUs)'),
  "  " + row('cfg5_B16', '5: 540×720, K=17, 2048 hyp, tn capped at 30 000, B=16', ' (round 2: 1.5847 ms, count kernel 1.4536)'),
  "  " + row('cfg5_B2_shard_of_8gpu', '5: same, B=2 (shard of 8 GPUs)'),
@@ -83,7 +83,7 @@ s = re.sub(r"Sum [0-9.]+ µs against 187 µs for the full kernel on the same box
 ab = {r['case']: r for r in json.load(open('profiles/r03_staged_ab.json'))}
 notes = {'cfg3:8': 'not staged by AUTO (two extra launches on a latency-bound call)', 'cfg3:16': 'staged by AUTO from here on (2.3·10¹⁰)',
          'cfg3:32': '', 'cfg3:64': '**the benchmark workload**',
-         'cfg4:32': 'staged by AUTO, nothing to stage (tn ≈ 0.5–2 k: every image below 8 chunks): the first launch counts everything, `k_lead` and the filter launch find the `any_staged` word 0 and leave at once — the price of the host not knowing `tn`',
+         'cfg4:32': 'nothing to stage (tn ≈ 0.5–2 k: every image below 8 chunks): forced, the first launch counts everything and `k_lead` and the filter launch find the `any_staged` word 0 and leave at once; AUTO learns the images\' `tn` (and ρ = 0.63) from the stage hint and does not stage from the second call on',
          'cfg5:16': '540×720, K = 17, 2048 hypotheses, tn = 30 000'}
 label = {'cfg3:8': 'config 3, B = 8', 'cfg3:16': 'config 3, B = 16', 'cfg3:32': 'config 3, B = 32', 'cfg3:64': 'config 3, **B = 64**',
          'cfg4:32': 'config 4, B = 32', 'cfg5:16': 'config 5, B = 16'}

@@ -63,9 +63,8 @@
 
 {{table}}
 
-  Config 4 at B = 32 is the one row that lost against round 2 (0.1016 → {{cfg4_ms}} ms per call): AUTO stages it, every
-  image is below 8 chunks, the first launch counts everything and the two later launches leave at once — the host cannot
-  know `tn` (§4.6).  Host side: one call costs 27–32 µs of host time on an idle stream, so below B ≈ 2 the eager wall clock
+  Config 4 at B = 32 (sparse masks: nothing to stage; round 2: 0.1016 ms per call) takes {{cfg4_ms}} ms: the first call stages,
+  finds every image below 8 chunks, and from then on the stage hint keeps AUTO on the full pass (§4.6).  Host side: one call costs 27–32 µs of host time on an idle stream, so below B ≈ 2 the eager wall clock
   is host-bound; a captured graph removes that (the replay column).  **Small batches: the floor stays where round 2 left
   it** (B = 1: 33–35 µs, B = 8: 62–65 µs, default path ≈ 0.93 M images/s; VERDICT r1's targets 20 / 45 µs / 1.5 M are not
   met).  The path has five dependent phases between the mask and the keypoints and each costs 2.5–5 µs as a launch or
