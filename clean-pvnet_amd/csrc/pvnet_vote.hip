@@ -270,12 +270,14 @@ Bf16Consts bf16_consts(float thresh)
     const double T = (double)thresh, s2 = 1.0 - T * T, kappa = T / std::sqrt(s2);
     const double u = 0x1p-24;
     Bf16Consts fc;
-    fc.beta = (float)(1.25 * (32.0 * (1.0 + kappa) + 8.0 / s2) * u / T);
-    fc.eps_c = (float)(1.25 * (1.0 + kappa) * 34.0 * u);
+    // (round 3: the unit normals come from v_rsq_f32, components within 4u instead of the 3u of sqrt + divide: 32 -> 33,
+    // 34 -> 35 in the first level, 6 -> 8 in the second)
+    fc.beta = (float)(1.25 * (33.0 * (1.0 + kappa) + 8.0 / s2) * u / T);
+    fc.eps_c = (float)(1.25 * (1.0 + kappa) * 35.0 * u);
     fc.eps0 = (float)(1.5e-6 * (1.0 + kappa));
     fc.kappa = (float)kappa;
-    // second level: d exact-path's own, nh/B computed in f32 (<= 2u / 3u relative), one fma each => 6u(1+kappa)|d|
-    fc.beta2 = (float)(1.25 * (6.0 * (1.0 + kappa) + 8.0 / s2) * u / T);
+    // second level: d exact-path's own, nh/B computed in f32 (<= 4u / 5u relative), one fma each => 8u(1+kappa)|d|
+    fc.beta2 = (float)(1.25 * (8.0 * (1.0 + kappa) + 8.0 / s2) * u / T);
 #ifdef PVV_TUNING
     // timing experiments only (tools/build_variant.sh -DPVV_TUNING); != 1 voids the exactness guarantee
     static const char *dbg = getenv("PVV_DEBUG_BAND_SCALE");

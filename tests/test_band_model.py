@@ -42,11 +42,65 @@ def samples(n, T, seed, spread):
     return cx, cy, hx, hy, nx, ny
 
 
+def rsq_unit_normal(nx, ny, seed):
+    """The kernels' unit normal: dd = fl(nx^2 + ny^2) in binary32, r = v_rsq_f32(dd) modelled as the correctly rounded
+    1/sqrt perturbed by an adversarial +-1 ulp (measured on MI355X over all normal inputs: <= 0.8633 ulp,
+    tools/microbench/rsq_accuracy.hip), n = (fl(nx r), fl(ny r))."""
+    rng = np.random.RandomState(seed)
+    with np.errstate(all="ignore"):
+        dd = nx * nx + ny * ny
+        r = (1.0 / np.sqrt(dd.astype(np.float64))).astype(f32)
+        r = np.nextafter(r, np.where(rng.rand(len(r)) < 0.5, f32(np.inf), f32(-np.inf)).astype(f32))
+        return nx * r, ny * r, dd
+
+
+DD_ALIVE = np.array([0x2b8cbcce], dtype=np.uint32).view(f32)[0]     # count_bf16.hpp: kDdAlive
+
+
+def test_dead_pixel_threshold_is_the_exact_reject():
+    """K:121 rejects a pixel when (double)sqrtf(dd) < 1e-6; sqrtf is monotone, so that is a threshold on dd: kDdAlive must
+    be the smallest binary32 the exact test lets through (and the constant in the source must be this one)."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "clean-pvnet_amd", "csrc", "count_bf16.hpp")).read()
+    m = re.search(r"#define kDdAlive __uint_as_float\(0x([0-9a-f]+)u\)", src)
+    assert m and int(m.group(1), 16) == 0x2b8cbcce
+    below = np.nextafter(DD_ALIVE, f32(0))
+    assert not (np.float64(np.sqrt(DD_ALIVE)) < 1e-6) and (np.float64(np.sqrt(below)) < 1e-6)
+    xs = np.arange(0x2b8cbcce - 5000, 0x2b8cbcce + 5000, dtype=np.uint32).view(f32)
+    assert np.array_equal(xs >= DD_ALIVE, ~(np.sqrt(xs).astype(np.float64) < 1e-6))
+
+
+@pytest.mark.parametrize("T", [0.9, 0.99, 0.999])
+def test_second_level_band_with_rsq_normals(T):
+    """k_count_bf16's second level as the kernel runs it from round 3 on: d = fl(h - c), the unit normal from v_rsq_f32
+    (components within 4u), B = kappa perp(n) in f32, one fma each; band beta2 = 1.25 (8 (1+kappa) + 8/(1-T^2)) u / T,
+    eps0.  Outside the band the decision is the exact one."""
+    n = 2_000_000
+    Td = np.float64(f32(T)); s2 = 1 - Td * Td; kappa = Td / np.sqrt(s2)
+    beta = f32(1.25 * (8 * (1 + kappa) + 8 / s2) * U / Td)
+    eps = f32(1.5e-6 * (1 + kappa))
+    kf = f32(kappa)
+    band_angle = float(beta) * Td * np.sqrt(s2)
+    cx, cy, hx, hy, nx, ny = samples(n, T, 31, spread=5 * band_angle / np.arccos(Td))
+    ux, uy, _dd = rsq_unit_normal(nx, ny, 32)
+    bx, by = -kf * uy, kf * ux
+    dx, dy = hx - cx, hy - cy
+    a = fma32(dx, ux, dy * uy)
+    b = fma32(dx, bx, dy * by)
+    t = a - np.abs(b)
+    outside = fma32(np.full(n, -beta, f32), a, np.abs(t)) > eps
+    ex = exact_decision(cx, cy, hx, hy, nx, ny, T)
+    assert (outside.mean() > 0.1) and ((~outside).mean() > 0.005)
+    assert np.array_equal((t > 0)[outside], ex[outside])
+    assert ((t > 0) != ex).sum() > 0
+
+
 @pytest.mark.parametrize("T", [0.9, 0.99, 0.999])
 def test_packed_valu_band(T):
-    """The sqrt/divide-free decision on f32 operands (round 1's k_count_fast, now the model of k_count_bf16's second level,
-    whose f32-computed unit normals get the wider beta2): d = fl(h-c); nh, B binary64 quotients rounded once;
-    a = fma(dx,nhx, dy*nhy); t = a - |b'|."""
+    """The sqrt/divide-free decision on f32 operands with binary64 quotients rounded once as normals (round 1's
+    k_count_fast; the second level of k_count_bf16 as it runs today is test_second_level_band_with_rsq_normals above):
+    d = fl(h-c); a = fma(dx,nhx, dy*nhy); t = a - |b'|."""
     n = 2_000_000
     Td = np.float64(f32(T)); s2 = 1 - Td * Td; kappa = Td / np.sqrt(s2)
     beta = f32(1.25 * (3 * (1 + kappa) + 8 / s2) * U / Td)
@@ -87,18 +141,17 @@ def test_split_bf16_prefilter_band(T):
     bf16_consts.  C1 = the block extent."""
     n = 1_000_000
     Td0 = np.float64(f32(T)); s20 = 1 - Td0 * Td0; k0 = Td0 / np.sqrt(s20)
-    beta0 = 1.25 * (32 * (1 + k0) + 8 / s20) * U / Td0
+    beta0 = 1.25 * (33 * (1 + k0) + 8 / s20) * U / Td0
     cx, cy, hx, hy, nx, ny = samples(n, T, 12, spread=5 * beta0 * Td0 * np.sqrt(s20) / np.arccos(Td0))
     rng = np.random.RandomState(5)
     ox = (cx - rng.randint(0, 120, n)).astype(f32)                         # block origin: within ~120 px, integer
     oy = (cy - rng.randint(0, 4, n)).astype(f32)
     C1 = f32(124.0)
     Td = np.float64(f32(T)); s2 = 1 - Td * Td; kappa = Td / np.sqrt(s2)
-    beta = f32(1.25 * (32 * (1 + kappa) + 8 / s2) * U / Td)
-    eps = f32(1.25 * (1 + kappa) * 34 * U) * C1 + f32(1.5e-6 * (1 + kappa))
+    beta = f32(1.25 * (33 * (1 + kappa) + 8 / s2) * U / Td)
+    eps = f32(1.25 * (1 + kappa) * 35 * U) * C1 + f32(1.5e-6 * (1 + kappa))
     kf = f32(kappa)
-    norm1 = np.sqrt(nx * nx + ny * ny)
-    ux, uy = nx / norm1, ny / norm1                                        # binary32, as the kernel
+    ux, uy, _dd = rsq_unit_normal(nx, ny, 13)                              # binary32 with v_rsq_f32, as the kernel
     bx, by = -kf * uy, kf * ux
     cpx, cpy = cx - ox, cy - oy
     cn = -(cpx * ux + cpy * uy)
@@ -134,7 +187,7 @@ def test_lead_sure_inlier_test_is_a_lower_bound(T):
     closely than the band."""
     n = 2_000_000
     Td = np.float64(f32(T)); s2 = 1 - Td * Td; kappa = Td / np.sqrt(s2)
-    beta2 = 1.25 * (6 * (1 + kappa) + 8 / s2) * U / Td
+    beta2 = 1.25 * (8 * (1 + kappa) + 8 / s2) * U / Td
     beta, eps = f32(2 * f32(beta2)), f32(2 * f32(1.5e-6 * (1 + kappa)))
     kf = f32(kappa)
     cx, cy, hx, hy, nx, ny = samples(n, T, 21, spread=6 * 2 * beta2 * Td * np.sqrt(s2) / np.arccos(Td))
