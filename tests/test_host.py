@@ -274,3 +274,30 @@ def test_count_kernel_isa_guard(tmp_path):
         # spilled registers are tolerated in the per-item prologue and the rare exact path only: every scratch access
         # lies before the first or after the last matrix-core instruction (checked above), and there are few of them
         assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1)) <= 16, frag
+
+
+def test_stage_hint_thresholds_and_no_data_without_a_gpu():
+    """pvv_stage_hint_query: without a device there is no hint (returns 0, mean -1) and the threshold AUTO would compare it
+    with is the documented fit: 0.906 for config 3 at B = 64, 0.976 at B = 16, 0.66 for config 5 at
+    B = 16, clamped to [0.5, 0.985]."""
+    import ctypes
+    from tests import capi
+    L = capi.load()
+
+    def thr(B, H, W, K, hn):
+        p = capi.Problem()
+        p.B, p.H, p.W, p.K, p.hn = B, H, W, K, hn
+        mean, t = ctypes.c_float(7.0), ctypes.c_float(7.0)
+        rc = L.pvv_stage_hint_query(ctypes.byref(mean), ctypes.byref(t), ctypes.byref(p), None)
+        import torch
+        if not torch.cuda.is_available():
+            assert rc == 0 and mean.value == -1.0
+        return t.value
+
+    assert abs(thr(64, 480, 640, 9, 512) - 0.906) < 2e-3
+    assert abs(thr(16, 480, 640, 9, 512) - 0.976) < 2e-3
+    assert abs(thr(16, 540, 720, 17, 2048) - 0.662) < 5e-3
+    assert thr(1, 64, 64, 1, 128) == pytest.approx(0.985) and thr(1024, 2000, 2000, 64, 4096) == pytest.approx(0.5)
+    mean, t = ctypes.c_float(7.0), ctypes.c_float(7.0)
+    L.pvv_stage_hint_query(ctypes.byref(mean), ctypes.byref(t), None, None)
+    assert t.value == -1.0
