@@ -15,12 +15,16 @@
 // back and invalidates the XCD's L2 on gfx950 and cost 30 % of the whole call.)
 constexpr int kRefitSplitMax = 8;
 
+// BAND: the re-vote through the guard-band prefilter (large grids: VALU-bound) or the exact sequence alone (small ones:
+// a latency chain, where the prefilter's extra instructions only add to it: +1.2 % per call at B = 1)
+template <bool BAND>
 __global__ __launch_bounds__(kBlock) void k_select_refit(
     const int *__restrict__ tn_arr, const float2 *__restrict__ coords,
     const float2 *__restrict__ dirs, const float2 *__restrict__ hyps,
     const int *__restrict__ counts, double *__restrict__ sums /*[B,K,nsplit,5]*/,
     int *__restrict__ win_counts /*[B,K] or null*/, int K, int hn, int hstride /*row length of hyps / counts (>= hn)*/,
-    int cap, float thresh, int nsplit, float *__restrict__ win_ratio /*[B,K]: winner count / tn (k_finalize_v3's stage hint)*/)
+    int cap, float thresh, int nsplit, float *__restrict__ win_ratio /*[B,K]: winner count / tn (k_finalize_v3's stage hint)*/,
+    Bf16Consts fc /*kappa, beta2, eps0: the count kernel's second-level test, here the prefilter of the re-vote*/)
 {
     __shared__ int s_cnt[4], s_idx[4];
     __shared__ double red5[20];
@@ -59,6 +63,7 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
     float2 win = make_float2(0.f, 0.f);
     if (best > 0) win = hyps[(size_t)bk * hstride + besti];
 
+    const bool win_near = fabsf(win.x) < 1e15f && fabsf(win.y) < 1e15f;   // (beyond: the exact vote's squares overflow, the test's do not)
     // P:176-191: re-vote the winner (hn = 1) and accumulate the normal equations in binary64
     const float2 *dp = dirs + (size_t)bk * cap;
     const float2 *cq = coords + (size_t)b * cap;
@@ -76,7 +81,29 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (!vote_exact(c[u].x, c[u].y, win.x, win.y, d[u].x, d[u].y, thresh)) continue;
+            // The re-vote decides like the count kernel's second level (count_bf16.hpp): t = a - kappa |d x n|
+            // with the unit direction from v_rsq_f32, taken when it lies outside the guard band (beta2, eps0) -- ~15 VALU
+            // instructions -- and the exact sequence of K:100-125 (two square roots, a division: ~50) only inside the band
+            // (4e-5 of the pixels), for a dead direction and for a winner beyond 1e15 px.  Same inlier set, bit for bit.
+            bool inlier;
+            if constexpr (BAND) {
+                const float dd = d[u].x * d[u].x + d[u].y * d[u].y;
+                const float rinv = __builtin_amdgcn_rsqf(dd);
+                const float ux = d[u].x * rinv, uy = d[u].y * rinv;
+                const float dx = win.x - c[u].x, dy = win.y - c[u].y;
+                const float a2 = __builtin_fmaf(dx, ux, dy * uy);
+                const float b2 = __builtin_fmaf(dx, -fc.kappa * uy, dy * (fc.kappa * ux));
+                const float t2 = a2 - fabsf(b2);
+                inlier = t2 > 0.f;
+                const bool unsure = !win_near || !(dd >= kDdAlive && dd < INFINITY) ||
+                                    !(__builtin_fmaf(-fc.beta2, a2, fabsf(t2)) > fc.eps0);
+                if (__any(unsure)) {
+                    if (unsure) inlier = vote_exact(c[u].x, c[u].y, win.x, win.y, d[u].x, d[u].y, thresh);
+                }
+            } else {
+                inlier = vote_exact(c[u].x, c[u].y, win.x, win.y, d[u].x, d[u].y, thresh);
+            }
+            if (!inlier) continue;
             double nx = (double)d[u].y, ny = -(double)d[u].x;          // P:178-179
             double bb = nx * (double)c[u].x + ny * (double)c[u].y;     // P:189
             xx += nx * nx; xy += nx * ny; yy += ny * ny;               // P:190

@@ -1203,3 +1203,55 @@ def test_float_masks_and_strided_slices(oracle, synth, pkg, gpu):
     _m, wantc = oracle.estimate_voting_distribution_with_mean(_np(fm2), _np(vertex), _np(mean), 64, 128, idxs=_np(ii))
     _m2, cov = estimate_voting_distribution_with_mean(fm2.to(gpu), vertex.to(gpu), mean.to(gpu), 64, 128, idxs=ii.to(gpu))
     tol.assert_cov_close(_np(cov), wantc)
+
+
+@pytest.mark.parametrize("thresh", [0.99, 0.999, 0.9])
+def test_refit_band_prefilter_equals_the_exact_revote_on_adversarial_images(oracle, synth, pkg, gpu, thresh):
+    """k_select_refit<BAND> (B*K >= 128): the winner's re-vote goes through the second-level guard-band test and only
+    in-band pixels through the exact sequence.  Images whose hypotheses all meet in one point and whose other pixels are
+    aimed at the threshold cone of THAT point (relative angle 1 +- 2e-6) or straight at it: thousands of pixels per keypoint
+    sit in or beside the band of the winner.  Means and winner counts must equal those of PVV_COUNT_EXACT (whose refit is
+    the exact sequence for every pixel) bit for bit, and the oracle's within the contract."""
+    from clean_pvnet_amd import ransac_voting as ext
+    K, hn, nimg = 4, 64, 8
+    masks, verts, idxl = [], [], []
+    ang0 = np.arccos(np.float64(np.float32(thresh)))
+    for s in range(nimg):
+        c = {**synth.CONFIGS["cfg1"], "B": 1, "K": K, "fg": 0.12}
+        d = synth.make_batch(**c, seed=300 + s)
+        mask, vertex = d["mask"], d["vertex"].clone()
+        fg, coords, direct = oracle.compact_v3(_np(mask[0]), _np(vertex[0]))
+        tn = coords.shape[0]
+        rng = np.random.RandomState(300 + s)
+        kp = _np(d["kpt_2d"][0]).astype(np.float64)                    # [K,2]
+        used = rng.choice(tn, 40, replace=False)
+        ys, xs = coords[:, 1].astype(int), coords[:, 0].astype(int)
+        for ti in range(tn):
+            for vi in range(K):
+                dd = kp[vi] - coords[ti]
+                base = np.arctan2(dd[1], dd[0])
+                if ti in used or rng.rand() < 0.5:
+                    off = 0.0                                          # straight at the keypoint
+                else:
+                    off = ang0 * (1 + rng.uniform(-2e-6, 2e-6)) * rng.choice([-1, 1])
+                sc = rng.choice([1.0, 0.37, 12.5])
+                vertex[0, ys[ti], xs[ti], vi, 0] = float(np.cos(base + off) * sc)
+                vertex[0, ys[ti], xs[ti], vi, 1] = float(np.sin(base + off) * sc)
+        masks.append(mask); verts.append(vertex)
+        idxl.append(torch.from_numpy(used[rng.randint(0, 40, size=(hn, K, 2))].astype(np.int32))[None])
+    mask = torch.cat(masks * 4); vertex = torch.cat(verts * 4); idxs = torch.cat(idxl * 4)      # B = 32: B*K = 128
+    m, v, i = mask.to(gpu), vertex.to(gpu), idxs.to(gpu)
+    res = {}
+    for name, k in (("auto", ext.COUNT_AUTO), ("exact", ext.COUNT_EXACT)):
+        out, win, tnn, _ws = ext.ransac_voting_v3(m, v, hn, thresh, 5, 30000, i, None, 0, ext.SINGULAR_ZERO, count_kernel=k)
+        res[name] = (out.cpu(), win.cpu(), tnn.cpu())
+    for a_, b_ in zip(res["auto"], res["exact"]):
+        assert torch.equal(a_, b_)
+    det = []
+    want = oracle.ransac_voting_layer_v3(_np(mask[:nimg]), _np(vertex[:nimg]), hn, thresh, idxs=_np(idxs[:nimg]), singular="zero",
+                                         details=det)
+    np.testing.assert_array_equal(_np(res["auto"][1][:nimg]), np.stack([r["win_counts"] for r in det]))
+    tol.assert_means_close(_np(res["auto"][0][:nimg]), want)
+    # the construction works: the winners count about half of the pixels, and many others sit within 1e-5 of the threshold
+    tn0 = int(res["auto"][2][0])
+    assert 0.3 * tn0 < int(res["auto"][1][0].min()) and int(res["auto"][1][0].max()) < 0.8 * tn0
