@@ -31,8 +31,12 @@ struct MaskArgs {
     int *tn_user;            // the caller's tn[B] (or nullptr): written beside the workspace copy, no D2D copy later
     int *status;             // the caller's status[B] (or nullptr): PVV_STATUS_* bits, written with tn
     int fuse_sub;            // 1: k_compact_hyp applies the subsampling itself (no k_tile_subsample launch), see there
-    int want_draws;          // 1: subsampling is possible at all (max_num below the largest foreground_num the mask can
-                             //    have): k_tile_scan stores every foreground pixel's U(0,1) draw beside its list entry
+    int want_draws;          // 1: k_tile_scan stores every foreground pixel's U(0,1) draw beside its list entry -- when
+                             //    subsampling is possible at all (max_num below the largest foreground_num the mask can have)
+                             //    AND has its own pass (k_tile_subsample, !fuse_sub: subsampling is likely).  With fused
+                             //    subsampling (unlikely by the host's rule) the few consumers evaluate the draw of a listed
+                             //    pixel on demand (list_draw): the scan of a batch that never subsamples -- the benchmark --
+                             //    then neither runs the generator nor writes 4 bytes per foreground pixel (-1.3 % per call)
     // fused argmax (decode_keypoint): when seg != nullptr the mask value is argmax_c seg[b,c,y,x]
     const float *seg;
     long long *mask_out;     // [B,H,W] int64 or nullptr
@@ -93,6 +97,15 @@ __device__ __forceinline__ float selection_draw(const MaskArgs &a, int b, int p)
 {
     if (a.selection) return a.selection[(int64_t)b * a.HW + p];
     return (float)(rng_u32(a.seed, 0u, (uint32_t)(a.b0 + b), (uint32_t)p) >> 8) * 0x1p-24f;
+}
+
+// Draw of entry e of tile i's list: stored by the scan (draws != nullptr) or evaluated on demand from the (image, pixel)
+// key -- the same number either way.
+__device__ __forceinline__ float list_draw(const MaskArgs &a, int b, int i, int e, const unsigned short *__restrict__ lists /*of image b*/,
+                                           const float *__restrict__ draws /*of image b, or nullptr*/)
+{
+    if (draws) return draws[(size_t)i * kTile + e];
+    return selection_draw(a, b, i * kTile + (int)lists[(size_t)i * kTile + e]);
 }
 
 // Exclusive scan of the 32 (step, wave) segment counts of a tile by wave 0; seg[32] = the tile's total.
@@ -232,10 +245,12 @@ __device__ __forceinline__ ImageTotals image_totals(const uint32_t *__restrict__
 
 // Filter one tile's list by the subsample draw (keep iff U < prob), order kept: survivors land in out[] (LDS or
 // global, may alias nothing), their number is returned to every thread.  seg: kTileSteps*4+1 ints of LDS.
-__device__ __forceinline__ int filter_tile_list(int nz, float prob, const unsigned short *__restrict__ list,
-                                                const float *__restrict__ draw, unsigned short *out, int *seg)
+__device__ __forceinline__ int filter_tile_list(const MaskArgs &a, int b, int t, int nz, float prob,
+                                                const unsigned short *__restrict__ img_lists, const float *__restrict__ img_draws /*or nullptr*/,
+                                                unsigned short *out, int *seg)
 {
     const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const unsigned short *list = img_lists + (size_t)t * kTile;
     unsigned long long m[kTileSteps];
     unsigned short off[kTileSteps];
 #pragma unroll
@@ -245,7 +260,7 @@ __device__ __forceinline__ int filter_tile_list(int nz, float prob, const unsign
         off[s] = 0;
         if (e < nz) {
             off[s] = list[e];
-            f = draw[e] < prob;
+            f = (img_draws ? img_draws[(size_t)t * kTile + e] : selection_draw(a, b, t * kTile + (int)off[s])) < prob;
         }
         m[s] = __ballot(f);
         if (lane == 0) seg[s * 4 + wave] = __popcll(m[s]);
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_subsample(MaskArgs a, uint32_t 
     if (tot.fg <= (long long)a.max_num) return;
     const float prob = (float)a.max_num / (float)tot.fg;
     unsigned short *list = tile_list + ((size_t)b * a.T + t) * kTile;
-    const int n = filter_tile_list(nz, prob, list, tile_draw + ((size_t)b * a.T + t) * kTile, keep, seg);
+    const int n = filter_tile_list(a, b, t, nz, prob, tile_list + (size_t)b * a.T * kTile, tile_draw + (size_t)b * a.T * kTile, keep, seg);
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += kBlock) list[i] = keep[i];
     // In place: the other blocks of the image may still be reading the table, but they only use the weight sums
@@ -363,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
     const int b = blockIdx.y;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const unsigned short *img_lists = tile_list + (size_t)b * a.T * kTile;
-    const float *img_draws = tile_draw + (size_t)b * a.T * kTile;
+    const float *img_draws = a.want_draws ? tile_draw + (size_t)b * a.T * kTile : nullptr;   // nullptr: on demand (list_draw)
 
     if ((int)blockIdx.x < h.blocks) {
         // ------------------------------------------------------------------ hypothesis block
@@ -411,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
                 const int ni = s_prefix[i] - (i ? s_prefix[i - 1] : 0);
                 for (int e0 = 0; e0 < ni; e0 += kBlock) {
                     const int e = e0 + threadIdx.x;
-                    const bool keep = e < ni && img_draws[(size_t)i * kTile + e] < prob;
+                    const bool keep = e < ni && list_draw(a, b, i, e, img_lists, img_draws) < prob;
                     const unsigned long long m = __ballot(keep);
                     __syncthreads();
                     if (lane == 0) red[wave] = __popcll(m);
@@ -478,11 +493,11 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
                     const uint32_t stry = stream + 16u + 4u * (uint32_t)tr;
                     if (p0 < 0) {
                         const int p = select_pixel(s_prefix, a.T, img_lists, (int)(rng_u32(a.seed, stry, img, c) % (uint32_t)total), &e);
-                        if (img_draws[e] < prob) p0 = p;
+                        if ((img_draws ? img_draws[e] : selection_draw(a, b, p)) < prob) p0 = p;
                     }
                     if (p1 < 0) {
                         const int p = select_pixel(s_prefix, a.T, img_lists, (int)(rng_u32(a.seed, stry, img, c + 1u) % (uint32_t)total), &e);
-                        if (img_draws[e] < prob) p1 = p;
+                        if ((img_draws ? img_draws[e] : selection_draw(a, b, p)) < prob) p1 = p;
                     }
                 }
                 if (p0 < 0 || p1 < 0) {                            // no survivor found (prob ~ 0): degenerate pair
@@ -532,13 +547,12 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
         int cnt = 0;
         for (int i = 0; i < t; ++i) {
             const int ni = (int)(tiles[b * a.T + i] & kTileNzMask);                 // block-uniform
-            const float *di = img_draws + (size_t)i * kTile;
             for (int e = threadIdx.x; e < ni; e += kBlock)
-                cnt += di[e] < prob ? 1 : 0;
+                cnt += list_draw(a, b, i, e, img_lists, img_draws) < prob ? 1 : 0;
         }
         before = block_sum(cnt, red);
         __syncthreads();
-        tile_n = filter_tile_list(nz, prob, my_list, img_draws + (size_t)t * kTile, list, seg);
+        tile_n = filter_tile_list(a, b, t, nz, prob, img_lists, img_draws, list, seg);
         __syncthreads();
         if (t == a.T - 1 && threadIdx.x == 0) {                                    // the last tile knows the subsampled total
             const int all = before + tile_n;

@@ -492,7 +492,7 @@ Front make_front(const pvv_problem *p, int mode, const void *d_mask, const float
     // largest possible foreground_num: the sum of byte values (P:126), of class indices (fused argmax) or of ones (P:208)
     const long long max_weight = mode == 1 ? 1 : (d_seg ? (p->seg_classes > 1 ? p->seg_classes - 1 : 1) : 255);
     f.can_subsample = (long long)p->max_num < max_weight * (long long)p->H * p->W;
-    m.want_draws = f.can_subsample ? 1 : 0;
+    m.want_draws = (f.can_subsample && !m.fuse_sub) ? 1 : 0;     // fused subsampling evaluates its draws on demand (compaction.hpp)
     VertexArgs &v = f.v;
     v.vertex = d_vertex;
     v.sb = p->vertex_stride[0]; v.sh = p->vertex_stride[1]; v.sw = p->vertex_stride[2];

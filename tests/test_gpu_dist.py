@@ -107,7 +107,8 @@ for name, batch, cfgname in (("b5", 5, "cfg1"), ("b1", 1, "cfg1"), ("b3_480x640"
     res[name] = dict(shard=[lo, hi], equal=bool(torch.equal(got, want)), cov_equal=bool(torch.equal(cov_all, cov_want)),
                      shape=list(got.shape), err=float((got - d["kpt_2d"]).abs().max()))
 torch.cuda.synchronize()
-print("RESULT " + json.dumps(dict(rank=rank, world=dist.get_world_size(), backend=dist.get_backend(), res=res)), flush=True)
+out = json.dumps(dict(rank=rank, world=dist.get_world_size(), backend=dist.get_backend(), res=res))
+open(os.path.join(os.environ["PVV_TEST_OUT"], "rank%%d.json" %% rank), "w").write(out)      # (one pipe for two ranks garbles lines)
 dist.barrier()
 dist.destroy_process_group()
 """ % ROOT
@@ -121,9 +122,9 @@ def test_hip_layer_in_a_world_of_two_ranks_on_one_gpu_uneven_shards(gpu, tmp_pat
     script.write_text(_TWO_RANKS)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29535", str(script)]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=_env(), timeout=900, cwd=ROOT)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(_env(), PVV_TEST_OUT=str(tmp_path)), timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
-    lines = [json.loads(l.split("RESULT ", 1)[1]) for l in r.stdout.splitlines() if "RESULT " in l]
+    lines = [json.load(open(tmp_path / ("rank%d.json" % k))) for k in (0, 1)]
     assert sorted(x["rank"] for x in lines) == [0, 1]
     for x in lines:
         assert x["world"] == 2 and x["backend"] == "gloo"
