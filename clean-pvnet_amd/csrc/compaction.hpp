@@ -115,13 +115,8 @@ __device__ __forceinline__ void scan_segments(int *seg)
     __syncthreads();
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
-        int c = lane < kTileSteps * 4 ? seg[lane] : 0;
-        int inc = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int n = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += n;
-        }
+        const int c = lane < kTileSteps * 4 ? seg[lane] : 0;
+        const int inc = wave_incl_scan(c);
         if (lane < kTileSteps * 4) seg[lane] = inc - c;
         if (lane == kTileSteps * 4 - 1) seg[kTileSteps * 4] = inc;
     }
@@ -140,7 +135,7 @@ template <> struct RawElem<2> { typedef uint16_t type; };
 template <> struct RawElem<4> { typedef uint32_t type; };
 template <> struct RawElem<8> { typedef uint64_t type; };
 
-template <int ES, bool AHEAD>
+template <int ES, bool AHEAD, int MODE /*MaskArgs.mode, compile-time here*/>
 __global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__restrict__ tiles,
                                                       unsigned short *__restrict__ tile_list,
                                                       float *__restrict__ tile_draw, int total_tiles)
@@ -149,33 +144,35 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__re
     __shared__ int seg2[2][kTileSteps * 4 + 1];                    // double-buffered by the parity of the iteration: the
     __shared__ int red2[2][4];                                     // next tile's counts are written while stragglers still read
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    // AHEAD (host: a.contig && !a.seg): the read-ahead instantiation
+    // AHEAD (host: a.contig && !a.seg): the read-ahead instantiation.  The kernel issues about as many instructions per tile
+    // as the memory system needs cycles to deliver it (round 3: ~400 per wave and tile against 16 KB per block), so the
+    // tile walk avoids what it can: (image, tile) advance by a constant step instead of two divisions per tile, and a tile
+    // that lies inside the image -- all but possibly the last one -- is loaded without per-element bounds checks.
     raw_t cur[AHEAD ? kTileSteps : 1] = {};
     int g = blockIdx.x;
-    if constexpr (AHEAD) if (g < total_tiles) {
-        const int b = g / a.T, t = g - b * a.T;
-        const raw_t *src = (const raw_t *)a.mask + (int64_t)b * a.sb + (int64_t)t * kTile;
+    int b = g / a.T, t = g - b * a.T;
+    const int step_b = (int)gridDim.x / a.T, step_t = (int)gridDim.x - step_b * a.T;
+    [[maybe_unused]] auto load_tile = [&](raw_t (&dst)[AHEAD ? kTileSteps : 1], int bi, int ti) {
+        const raw_t *src = (const raw_t *)a.mask + (int64_t)bi * a.sb + (int64_t)ti * kTile + threadIdx.x;
+        if ((ti + 1) * kTile <= a.HW) {
 #pragma unroll
-        for (int s = 0; s < kTileSteps; ++s) {
-            const int p = t * kTile + s * kBlock + threadIdx.x;
-            cur[s] = p < a.HW ? src[s * kBlock + threadIdx.x] : (raw_t)0;
+            for (int s = 0; s < kTileSteps; ++s) dst[AHEAD ? s : 0] = src[s * kBlock];
+        } else {
+#pragma unroll
+            for (int s = 0; s < kTileSteps; ++s)
+                dst[AHEAD ? s : 0] = ti * kTile + s * kBlock + (int)threadIdx.x < a.HW ? src[s * kBlock] : (raw_t)0;
         }
-    }
-    for (int it = 0; g < total_tiles; g += gridDim.x, ++it) {
-        const int b = g / a.T, t = g - b * a.T;
+    };
+    if constexpr (AHEAD) if (g < total_tiles) load_tile(cur, b, t);
+    for (int it = 0; g < total_tiles; ++it) {
         int *seg = seg2[it & 1], *red = red2[it & 1];
         raw_t nxt[AHEAD ? kTileSteps : 1] = {};
         const int gn = g + gridDim.x;
-        if constexpr (AHEAD) if (gn < total_tiles) {
-            const int bn = gn / a.T, tn = gn - bn * a.T;
-            const raw_t *src = (const raw_t *)a.mask + (int64_t)bn * a.sb + (int64_t)tn * kTile;
-#pragma unroll
-            for (int s = 0; s < kTileSteps; ++s) {
-                const int p = tn * kTile + s * kBlock + threadIdx.x;
-                nxt[s] = p < a.HW ? src[s * kBlock + threadIdx.x] : (raw_t)0;
-            }
-        }
+        int bn = b + step_b, tn = t + step_t;
+        if (tn >= a.T) { tn -= a.T; ++bn; }
+        if constexpr (AHEAD) if (gn < total_tiles) load_tile(nxt, bn, tn);
         unsigned long long m[kTileSteps];
+        int pc[kTileSteps];
         int sum = 0;
 #pragma unroll
         for (int s = 0; s < kTileSteps; ++s) {
@@ -183,32 +180,41 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__re
             int w = 0;
             if constexpr (AHEAD) {
                 const uint64_t v = (uint64_t)cur[s];               // 0 beyond the image
-                w = a.mode == 0 ? (int)(v & 0xFF) : (v == 1 ? 1 : 0);
+                w = MODE == 0 ? (int)(v & 0xFF) : (v == 1 ? 1 : 0);
             } else if (p < a.HW) {
                 w = mask_weight<ES>(a, b, p);
             }
             m[s] = __ballot(w != 0);
-            if (lane == 0) seg[s * 4 + wave] = __popcll(m[s]);
+            pc[s] = __popcll(m[s]);                                // (scalar)
             sum += w;
         }
-        sum = wave_sum(sum);
-        if (lane == 0) red[wave] = sum;
+        // the weight sum only differs from the pixel count for byte masks with values above 1 (P:126 sums the BYTES)
+        if (MODE == 0) sum = wave_total(sum);
+        else sum = pc[0] + pc[1] + pc[2] + pc[3] + pc[4] + pc[5] + pc[6] + pc[7];
+        if (lane == 0) {
+#pragma unroll
+            for (int s = 0; s < kTileSteps; ++s) seg[s * 4 + wave] = pc[s];
+            red[wave] = sum;
+        }
         scan_segments(seg);
         if (threadIdx.x == 0)
             tiles[b * a.T + t] = (uint32_t)seg[kTileSteps * 4] | ((uint32_t)(red[0] + red[1] + red[2] + red[3]) << 12);
         unsigned short *list = tile_list + ((size_t)b * a.T + t) * kTile;
         float *draw = tile_draw + ((size_t)b * a.T + t) * kTile;
+        if (seg[kTileSteps * 4] != 0) {                            // (block-uniform: four tiles in five hold no foreground)
 #pragma unroll
-        for (int s = 0; s < kTileSteps; ++s)
-            if ((m[s] >> lane) & 1ull) {
-                const int r = seg[s * 4 + wave] + __popcll(m[s] & ((1ull << lane) - 1ull));
-                list[r] = (unsigned short)(s * kBlock + threadIdx.x);
-                if (a.want_draws) draw[r] = selection_draw(a, b, t * kTile + s * kBlock + threadIdx.x);
-            }
+            for (int s = 0; s < kTileSteps; ++s)
+                if ((m[s] >> lane) & 1ull) {
+                    const int r = seg[s * 4 + wave] + __popcll(m[s] & ((1ull << lane) - 1ull));
+                    list[r] = (unsigned short)(s * kBlock + threadIdx.x);
+                    if (a.want_draws) draw[r] = selection_draw(a, b, t * kTile + s * kBlock + threadIdx.x);
+                }
+        }
         if constexpr (AHEAD) {
 #pragma unroll
             for (int s = 0; s < kTileSteps; ++s) cur[s] = nxt[s];
         }
+        g = gn; b = bn; t = tn;
     }
 }
 

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 #include "pvnet_vote.h"
 
@@ -425,7 +426,7 @@ int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_
     return PVV_OK;
 }
 
-template <int ES>
+template <int ES, int MODE>
 void launch_scan(const MaskArgs &m, const Layout &L, char *ws, int B, hipStream_t st)
 {
     const long long total = (long long)L.T * B;
@@ -435,7 +436,7 @@ void launch_scan(const MaskArgs &m, const Layout &L, char *ws, int B, hipStream_
     // the read-ahead needs a contiguous mask; a strided mask or the fused argmax keep one short-lived block per tile
     // (their loads are not issued ahead, and a persistent block would walk its tiles one load latency at a time)
     if (!(m.contig && !m.seg)) {
-        hipLaunchKernelGGL((k_tile_scan<ES, false>), dim3((unsigned)total), dim3(kBlock), 0, st, m, tiles, lists, draws, (int)total);
+        hipLaunchKernelGGL((k_tile_scan<ES, false, MODE>), dim3((unsigned)total), dim3(kBlock), 0, st, m, tiles, lists, draws, (int)total);
         return;
     }
     // persistent over the B*T tiles: as many blocks as the chip holds at once, every block the same number of tiles (+-1)
@@ -444,13 +445,13 @@ void launch_scan(const MaskArgs &m, const Layout &L, char *ws, int B, hipStream_
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!per_cu[dev]) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile_scan<ES, true>, kBlock, 0) != hipSuccess || n < 1) n = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile_scan<ES, true, MODE>, kBlock, 0) != hipSuccess || n < 1) n = 4;
         per_cu[dev] = n > 8 ? 8 : n;
     }
     const long long resident = (long long)per_cu[dev] * num_cus();
     const long long per_block = (total + resident - 1) / resident;
     const int grid = (int)((total + per_block - 1) / per_block);
-    hipLaunchKernelGGL((k_tile_scan<ES, true>), dim3(grid), dim3(kBlock), 0, st, m, tiles, lists, draws, (int)total);
+    hipLaunchKernelGGL((k_tile_scan<ES, true, MODE>), dim3(grid), dim3(kBlock), 0, st, m, tiles, lists, draws, (int)total);
 }
 
 struct Front {
@@ -515,11 +516,16 @@ Front make_front(const pvv_problem *p, int mode, const void *d_mask, const float
 
 int run_scan(const pvv_problem *p, const Front &f, char *ws, const Layout &L, hipStream_t st)
 {
+    // (the mask's interpretation -- low byte for v3, == 1 for the estimate -- is a template parameter of the scan)
+    auto go = [&](auto es) {
+        constexpr int ES = decltype(es)::value;
+        if (f.m.mode == 0) launch_scan<ES, 0>(f.m, L, ws, p->B, st); else launch_scan<ES, 1>(f.m, L, ws, p->B, st);
+    };
     switch (f.m.es) {
-    case 1: launch_scan<1>(f.m, L, ws, p->B, st); break;
-    case 2: launch_scan<2>(f.m, L, ws, p->B, st); break;
-    case 4: launch_scan<4>(f.m, L, ws, p->B, st); break;
-    default: launch_scan<8>(f.m, L, ws, p->B, st); break;
+    case 1: go(std::integral_constant<int, 1>{}); break;
+    case 2: go(std::integral_constant<int, 2>{}); break;
+    case 4: go(std::integral_constant<int, 4>{}); break;
+    default: go(std::integral_constant<int, 8>{}); break;
     }
     return check_launch("k_tile_scan");
 }

@@ -58,6 +58,21 @@ __device__ __forceinline__ T wave_sum(T v)
     return v;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and broadcasts (no LDS crossbar: the six
+// ds_bpermute + wait pairs of a __shfl_up scan are ~350 cycles of latency, these eight VALU instructions ~40); lane 63
+// ends with the wave's total.
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);     // row_shr:8  -> inclusive within each row of 16
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int wave_total(int v) { return __builtin_amdgcn_readlane(wave_incl_scan(v), 63); }
+
 // Sum over the 256-thread block; result valid in every thread.  `red` holds >= 4 T.
 template <typename T>
 __device__ __forceinline__ T block_sum(T v, T *red)

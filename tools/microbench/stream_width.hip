@@ -43,6 +43,58 @@ __global__ __launch_bounds__(256) void k_tiles(const unsigned long long *__restr
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// the same with k_tile_scan's per-tile work added step by step: LEVEL 1 = + weight sum (wave reduction), 2 = + the segment
+// scan (two barriers, wave 0 scans the 32 segment counts), 3 = + the ordered 16-bit list stores, 4 = + the packed tile word
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_scanlike(const unsigned long long *__restrict__ src, size_t ntiles, uint32_t *__restrict__ sink,
+                                                  unsigned short *__restrict__ lists, uint32_t *__restrict__ tiles)
+{
+    __shared__ int seg2[2][33];
+    __shared__ int red2[2][4];
+    unsigned long long cur[8], nxt[8];
+    uint32_t acc = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    size_t g = blockIdx.x;
+    if (g < ntiles) for (int s = 0; s < 8; ++s) cur[s] = src[g * 2048 + s * 256 + threadIdx.x];
+    for (int it = 0; g < ntiles; g += gridDim.x, ++it) {
+        int *seg = seg2[it & 1], *red = red2[it & 1];
+        const size_t gn = g + gridDim.x;
+        if (gn < ntiles) for (int s = 0; s < 8; ++s) nxt[s] = src[gn * 2048 + s * 256 + threadIdx.x];
+        unsigned long long m[8];
+        int sum = 0;
+        for (int s = 0; s < 8; ++s) {
+            const int w = (int)(cur[s] & 0xff);
+            m[s] = __ballot(w != 0 && ((threadIdx.x + s * 256 + g) % 50 == 0));     // ~2 % foreground
+            if (lane == 0) seg[s * 4 + wave] = __popcll(m[s]);
+            sum += w;
+        }
+        if (LEVEL >= 1) {
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            if (lane == 0) red[wave] = sum;
+        }
+        if (LEVEL >= 2) {
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                int c = lane < 32 ? seg[lane] : 0, inc = c;
+                for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
+                if (lane < 32) seg[lane] = inc - c;
+                if (lane == 31) seg[32] = inc;
+            }
+            __syncthreads();
+        }
+        if (LEVEL >= 4 && threadIdx.x == 0) tiles[g] = (uint32_t)seg[32] | ((uint32_t)(red[0] + red[1] + red[2] + red[3]) << 12);
+        if (LEVEL >= 3) {
+            unsigned short *list = lists + g * 2048;
+            for (int s = 0; s < 8; ++s)
+                if ((m[s] >> lane) & 1ull) list[seg[s * 4 + wave] + __popcll(m[s] & ((1ull << lane) - 1ull))] = (unsigned short)(s * 256 + threadIdx.x);
+        } else {
+            for (int s = 0; s < 8; ++s) acc += __popcll(m[s]);
+        }
+        for (int s = 0; s < 8; ++s) cur[s] = nxt[s];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 int main()
 {
     const size_t bytes = 64ull * 480 * 640 * 8;
@@ -63,7 +115,20 @@ int main()
         }
         printf("%-44s %7.1f us  %7.1f GB/s (best %7.1f)\n", name, sum / 10 * 1e3, bytes / (sum / 10 * 1e-3) / 1e9, bytes / (best * 1e-3) / 1e9);
     };
-    for (int per_cu : {4, 8, 16}) {
+    unsigned short *lists; uint32_t *tiles;
+    hipMalloc(&lists, bytes / 8 * 2); hipMalloc(&tiles, bytes / 16384 * 4);
+    {
+        const int grid = 8 * cus;
+        printf("-- k_tile_scan's work added step by step, 8 blocks per CU\n");
+        time("tile-wise + ballots (level 0)", [&](void *b) { hipLaunchKernelGGL((k_scanlike<0>), dim3(grid), dim3(256), 0, 0, (const unsigned long long *)b, bytes / 16384, sink, lists, tiles); });
+        time("+ weight sum (1)", [&](void *b) { hipLaunchKernelGGL((k_scanlike<1>), dim3(grid), dim3(256), 0, 0, (const unsigned long long *)b, bytes / 16384, sink, lists, tiles); });
+        time("+ segment scan, two barriers (2)", [&](void *b) { hipLaunchKernelGGL((k_scanlike<2>), dim3(grid), dim3(256), 0, 0, (const unsigned long long *)b, bytes / 16384, sink, lists, tiles); });
+        time("+ ordered list stores (3)", [&](void *b) { hipLaunchKernelGGL((k_scanlike<3>), dim3(grid), dim3(256), 0, 0, (const unsigned long long *)b, bytes / 16384, sink, lists, tiles); });
+        time("+ tile word (4)", [&](void *b) { hipLaunchKernelGGL((k_scanlike<4>), dim3(grid), dim3(256), 0, 0, (const unsigned long long *)b, bytes / 16384, sink, lists, tiles); });
+        const int grid2 = 1920;
+        time("level 4, 1920 blocks (5 tiles each, as the scan)", [&](void *b) { hipLaunchKernelGGL((k_scanlike<4>), dim3(grid2), dim3(256), 0, 0, (const unsigned long long *)b, bytes / 16384, sink, lists, tiles); });
+    }
+    for (int per_cu : {8}) {
         const int grid = per_cu * cus;
         printf("-- %d blocks per CU\n", per_cu);
         time("16 B/lane x 4 in flight, nontemporal", [&](void *b) { hipLaunchKernelGGL((k_read<u32x4, 4, true>), dim3(grid), dim3(256), 0, 0, (const u32x4 *)b, bytes / 16, sink); });
