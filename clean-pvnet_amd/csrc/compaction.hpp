@@ -235,9 +235,9 @@ __device__ __forceinline__ ImageTotals image_totals(const uint32_t *__restrict__
         total += c;
         if (i < t) before += c;
     }
-    fgs = wave_sum(fgs);
-    before = wave_sum(before);
-    total = wave_sum(total);
+    fgs = wave_total(fgs);
+    before = wave_total(before);
+    total = wave_total(total);
     const int wave = threadIdx.x >> 6;
     __syncthreads();
     if (lane_id() == 0) { redl[wave] = fgs; red[wave] = before; red[4 + wave] = total; }
@@ -396,12 +396,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
             const int i = base + threadIdx.x;
             const uint32_t w = i < a.T ? tiles[b * a.T + i] : 0u;
             fgs += w >> 12;
-            int inc = (int)(w & kTileNzMask);
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int n = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += n;
-            }
+            const int inc = wave_incl_scan((int)(w & kTileNzMask));
             __syncthreads();
             if (lane == 63) red[wave] = inc;
             __syncthreads();
@@ -410,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
             if (i < a.T) s_prefix[i] = inc + off;
             carry += red[0] + red[1] + red[2] + red[3];
         }
-        fgs = wave_sum(fgs);
+        fgs = wave_total(fgs);
         __syncthreads();
         if (lane == 0) redl[wave] = fgs;
         __syncthreads();

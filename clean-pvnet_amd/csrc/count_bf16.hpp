@@ -202,12 +202,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 if (lane == 0) s_small[b0 >> 6] = sm;
                 inc = small ? (MODE == kCountFirst ? inc : 0) : stage_chunks<MODE == kCountFirst ? kStageFirst : kStageRest>(inc);
             }
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int m = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += m;
-            }
-            inc += carry;
+            inc = wave_incl_scan(inc) + carry;
             if (b < B) chunk_end[b] = inc;
             carry = __builtin_amdgcn_readlane(inc, 63);
         }
@@ -378,12 +373,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             }
             sP[pl] = rec;
         }
-        c1 = fmaxf(c1, __shfl_xor(c1, 32, 64));
-        c1 = fmaxf(c1, __shfl_xor(c1, 16, 64));
-        c1 = fmaxf(c1, __shfl_xor(c1, 8, 64));
-        c1 = fmaxf(c1, __shfl_xor(c1, 4, 64));
-        c1 = fmaxf(c1, __shfl_xor(c1, 2, 64));
-        c1 = fmaxf(c1, __shfl_xor(c1, 1, 64));
+        c1 = wave_max(c1);
         if (lane == 0) sRed[wave] = c1;
         // ---- B operands of the first group (see stage_group below for the layout)
         int far = 0;

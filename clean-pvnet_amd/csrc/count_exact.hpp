@@ -37,13 +37,7 @@ __device__ __forceinline__ int build_item_table(int *item_end, const int *__rest
                 const int tn = tn_arr ? tn_arr[b] : tn_fixed;
                 n = ((tn + pixels_per_chunk - 1) / pixels_per_chunk) * items_per_chunk;
             }
-            int inc = n;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int m = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += m;
-            }
-            inc += carry;
+            int inc = wave_incl_scan(n) + carry;
             if (b < B) item_end[b] = inc;
             carry = __builtin_amdgcn_readlane(inc, 63);
         }

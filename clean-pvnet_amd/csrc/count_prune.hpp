@@ -80,11 +80,7 @@ __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
         const int c = cp[h];
         if (c > best) { best = c; besth = h; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int oc = __shfl_xor(best, o, 64), oh = __shfl_xor(besth, o, 64);
-        if (oc > best || (oc == best && oh < besth)) { best = oc; besth = oh; }
-    }
+    wave_argmax_first(best, besth);
     if (lane == 0) { s_cnt[wave] = best; s_idx[wave] = besth; }
     __syncthreads();
     // the best kLead of the four per-wave leaders (count descending, index ascending); the bound L* comes from the overall
@@ -144,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
     }
 #pragma unroll
     for (int w = 0; w < kLead; ++w) {
-        const int s = wave_sum(inl[w]);
+        const int s = wave_total(inl[w]);
         if (lane == 0) s_sum[wave][w] = s;
     }
     __syncthreads();

@@ -47,11 +47,7 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
         int c = cp[h];
         if (c > best) { best = c; besti = h; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        int oc = __shfl_xor(best, o, 64), oi = __shfl_xor(besti, o, 64);
-        if (oc > best || (oc == best && oi < besti)) { best = oc; besti = oi; }
-    }
+    wave_argmax_first(best, besti);
     if (lane_id() == 0) { s_cnt[threadIdx.x >> 6] = best; s_idx[threadIdx.x >> 6] = besti; }
     __syncthreads();
     best = s_cnt[0]; besti = s_idx[0];

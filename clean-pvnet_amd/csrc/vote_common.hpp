@@ -58,20 +58,62 @@ __device__ __forceinline__ T wave_sum(T v)
     return v;
 }
 
-// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and broadcasts (no LDS crossbar: the six
-// ds_bpermute + wait pairs of a __shfl_up scan are ~350 cycles of latency, these eight VALU instructions ~40); lane 63
-// ends with the wave's total.
+// Wave-wide scans and reductions on DPP row shifts and broadcasts (row_shr:1/2/4/8 inside each row of 16 lanes, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3: lane 63 ends with the combination of all 64 lanes).
+// No LDS crossbar: the six ds_bpermute + wait pairs of a __shfl scan are ~350 cycles of latency, these VALU instructions
+// ~40.  Used where the result is exact whatever the order (integer sums, maxima, arg-max with a first-index tie rule);
+// floating-point SUMS keep their butterfly (the order of the additions is part of the result).
+#define PVV_DPP(old, v, ctrl, rmask, bc) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rmask), 0xf, (bc))
+
+// inclusive prefix sum; lane 63 holds the wave's total
 __device__ __forceinline__ int wave_incl_scan(int v)
 {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);     // row_shr:8  -> inclusive within each row of 16
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
+    v += PVV_DPP(0, v, 0x111, 0xf, true);
+    v += PVV_DPP(0, v, 0x112, 0xf, true);
+    v += PVV_DPP(0, v, 0x114, 0xf, true);
+    v += PVV_DPP(0, v, 0x118, 0xf, true);
+    v += PVV_DPP(0, v, 0x142, 0xa, false);
+    v += PVV_DPP(0, v, 0x143, 0xc, false);
     return v;
 }
 __device__ __forceinline__ int wave_total(int v) { return __builtin_amdgcn_readlane(wave_incl_scan(v), 63); }
+
+__device__ __forceinline__ long long wave_total(long long v)
+{
+    auto step = [&](auto shift) {
+        const int lo = (int)(unsigned long long)v, hi = (int)((unsigned long long)v >> 32);
+        return (long long)(((unsigned long long)(unsigned)shift(hi) << 32) | (unsigned)shift(lo));
+    };
+    v += step([](int x) { return PVV_DPP(0, x, 0x111, 0xf, true); });
+    v += step([](int x) { return PVV_DPP(0, x, 0x112, 0xf, true); });
+    v += step([](int x) { return PVV_DPP(0, x, 0x114, 0xf, true); });
+    v += step([](int x) { return PVV_DPP(0, x, 0x118, 0xf, true); });
+    v += step([](int x) { return PVV_DPP(0, x, 0x142, 0xa, false); });
+    v += step([](int x) { return PVV_DPP(0, x, 0x143, 0xc, false); });
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned long long)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)v >> 32), 63);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// maximum over the wave (lanes without a partner in a step combine with themselves)
+__device__ __forceinline__ float wave_max(float v)
+{
+#define PVV_STEP(ctrl, rmask) v = fmaxf(v, __int_as_float(PVV_DPP(__float_as_int(v), __float_as_int(v), ctrl, rmask, false)))
+    PVV_STEP(0x111, 0xf); PVV_STEP(0x112, 0xf); PVV_STEP(0x114, 0xf); PVV_STEP(0x118, 0xf); PVV_STEP(0x142, 0xa); PVV_STEP(0x143, 0xc);
+#undef PVV_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// arg-max over the wave with torch.max's tie rule (the FIRST index among equal counts): best/idx of all lanes, in every lane
+__device__ __forceinline__ void wave_argmax_first(int &best, int &idx)
+{
+#define PVV_STEP(ctrl, rmask) { const int oc = PVV_DPP(best, best, ctrl, rmask, false), oi = PVV_DPP(idx, idx, ctrl, rmask, false); \
+                                if (oc > best || (oc == best && oi < idx)) { best = oc; idx = oi; } }
+    PVV_STEP(0x111, 0xf) PVV_STEP(0x112, 0xf) PVV_STEP(0x114, 0xf) PVV_STEP(0x118, 0xf) PVV_STEP(0x142, 0xa) PVV_STEP(0x143, 0xc)
+#undef PVV_STEP
+    best = __builtin_amdgcn_readlane(best, 63);
+    idx = __builtin_amdgcn_readlane(idx, 63);
+}
 
 // Sum over the 256-thread block; result valid in every thread.  `red` holds >= 4 T.
 template <typename T>
