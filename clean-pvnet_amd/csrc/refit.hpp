@@ -109,10 +109,7 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
     // one reduction for all five sums: five independent shuffle chains interleave, a single barrier
     double v[5] = {xx, xy, yy, bx, by};
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) v[i] += __shfl_xor(v[i], o, 64);
-    }
+    for (int i = 0; i < 5; ++i) v[i] = wave_total(v[i]);
     if (lane_id() == 0) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) red5[(threadIdx.x >> 6) * 5 + i] = v[i];

@@ -104,6 +104,26 @@ __device__ __forceinline__ float wave_max(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// sum of a double over the wave in the order of the row shifts (lane 63's chain); deterministic, but NOT the butterfly's
+// order: the last bits differ from a __shfl_xor tree
+__device__ __forceinline__ double wave_total(double v)
+{
+    auto step = [&](auto shift) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+        const unsigned long long r = ((unsigned long long)(unsigned)shift((int)(u >> 32)) << 32) | (unsigned)shift((int)u);
+        return __longlong_as_double((long long)r);
+    };
+    v += step([](int x) { return PVV_DPP(0, x, 0x111, 0xf, true); });
+    v += step([](int x) { return PVV_DPP(0, x, 0x112, 0xf, true); });
+    v += step([](int x) { return PVV_DPP(0, x, 0x114, 0xf, true); });
+    v += step([](int x) { return PVV_DPP(0, x, 0x118, 0xf, true); });
+    v += step([](int x) { return PVV_DPP(0, x, 0x142, 0xa, false); });
+    v += step([](int x) { return PVV_DPP(0, x, 0x143, 0xc, false); });
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)u, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // arg-max over the wave with torch.max's tie rule (the FIRST index among equal counts): best/idx of all lanes, in every lane
 __device__ __forceinline__ void wave_argmax_first(int &best, int &idx)
 {
