@@ -307,8 +307,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         if constexpr (FILTER) {
             R_rem = stage_pixels<kStageRest>(tn, (tn + PC - 1) / PC, PC);
             int full = lead_p >= 0 ? lead_p + lead_r : -1;
-            full = max(full, __shfl_xor(full, 1, 64));
-            full = max(full, __shfl_xor(full, 2, 64));
+            full = max(full, PVV_DPP(full, full, 0xB1, 0xf, false));   // quad_perm [1,0,3,2]
+            full = max(full, PVV_DPP(full, full, 0x4E, 0xf, false));   // quad_perm [2,3,0,1]: lanes 0-3 hold the four leaders' maximum
             lstar = __builtin_amdgcn_readfirstlane(full);
         }
         // kCountFilter: stage only the hypotheses of group g that can still reach L*, densely from slot 0 (order = pass,

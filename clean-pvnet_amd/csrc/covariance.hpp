@@ -36,8 +36,7 @@ __global__ __launch_bounds__(kBlock) void k_covariance(
     } else {
         int mx = 0;
         for (int h = threadIdx.x; h < hn; h += kBlock) mx = max(mx, cp[h]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+        mx = wave_max(mx);
         __syncthreads();
         if (lane_id() == 0) redi[threadIdx.x >> 6] = mx;
         __syncthreads();

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64) void k_finalize_v3(const int *__restrict__ tn_a
     if (hint) {
         float r = 0.f;
         for (int vi = threadIdx.x; vi < K; vi += 64) r += win_ratio[(size_t)b * K + vi];
-        r = wave_sum(r);
+        r = wave_total(r);                                         // (a hint: the order of the additions is irrelevant)
         if (threadIdx.x == 0) {
             hint[b] = skipped ? -1.f : r / (float)K;
             hint[hint_stride + b] = (float)tn_arr[b];              // (the host also learns whether any image is large enough to stage)

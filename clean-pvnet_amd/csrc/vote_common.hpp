@@ -124,6 +124,24 @@ __device__ __forceinline__ double wave_total(double v)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+__device__ __forceinline__ int wave_max(int v)
+{
+#define PVV_STEP(ctrl, rmask) v = max(v, PVV_DPP(v, v, ctrl, rmask, false))
+    PVV_STEP(0x111, 0xf); PVV_STEP(0x112, 0xf); PVV_STEP(0x114, 0xf); PVV_STEP(0x118, 0xf); PVV_STEP(0x142, 0xa); PVV_STEP(0x143, 0xc);
+#undef PVV_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// sum of a float over the wave (order of the row shifts): only where the last bits do not matter
+__device__ __forceinline__ float wave_total(float v)
+{
+#define PVV_STEP(ctrl, rmask, bc) v += __int_as_float(PVV_DPP(0, __float_as_int(v), ctrl, rmask, bc))
+    PVV_STEP(0x111, 0xf, true); PVV_STEP(0x112, 0xf, true); PVV_STEP(0x114, 0xf, true); PVV_STEP(0x118, 0xf, true);
+    PVV_STEP(0x142, 0xa, false); PVV_STEP(0x143, 0xc, false);
+#undef PVV_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // arg-max over the wave with torch.max's tie rule (the FIRST index among equal counts): best/idx of all lanes, in every lane
 __device__ __forceinline__ void wave_argmax_first(int &best, int &idx)
 {
@@ -139,7 +157,7 @@ __device__ __forceinline__ void wave_argmax_first(int &best, int &idx)
 template <typename T>
 __device__ __forceinline__ T block_sum(T v, T *red)
 {
-    v = wave_sum(v);
+    v = wave_total(v);
     __syncthreads();
     if (lane_id() == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
