@@ -578,33 +578,24 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
     }
     const int room = a.cap - before;                                     // rows left in the image's list
     const int n = tile_n < room ? tile_n : (room > 0 ? room : 0);
-    for (int i = threadIdx.x; i < n; i += kBlock) {
-        const int p = t * kTile + list[i];
-        const int y = p / a.W;
-        coords[(size_t)b * a.cap + before + i] = make_float2((float)(p - y * a.W), (float)y);
-    }
-    // n*K gathers of 8 bytes each; eight per thread in flight (all loads of a trip before its stores), otherwise every
-    // trip of the loop pays a full memory latency: 9 trips at K = 9 and ~250 foreground pixels per tile
-    constexpr int kGather = 8;
-    const int total_g = n * v.K;
-    for (int i0 = threadIdx.x; i0 < total_g; i0 += kGather * kBlock) {
-        float2 d[kGather];
-        size_t row[kGather];
+    // Row li of the tile: its pixel once (ONE division by W), then coords and the K gathers of 8 bytes -- all K in flight,
+    // consecutive threads on consecutive rows of every planar array.  (Rounds 1-2 flattened (keypoint, row) into one index
+    // and paid two integer divisions -- ~35 instructions each, there is no hardware divide -- per GATHER: ~600 instructions
+    // per thread and tile in a block whose whole life is a few microseconds.)
+    constexpr int kKeys = 12;                                            // gathers in flight per trip of the keypoint loop (K = 9: one trip)
+    for (int li = threadIdx.x; li < n; li += kBlock) {
+        const int p = t * kTile + list[li];
+        const int y = p / a.W, x = p - y * a.W;
+        coords[(size_t)b * a.cap + before + li] = make_float2((float)x, (float)y);
+        float2 *drow = dirs + (size_t)b * v.K * a.cap + before + li;
+        for (int v0 = 0; v0 < v.K; v0 += kKeys) {
+            float2 d[kKeys];
 #pragma unroll
-        for (int u = 0; u < kGather; ++u) {
-            const int i = i0 + u * kBlock;
-            d[u] = make_float2(0.f, 0.f);
-            row[u] = 0;
-            if (i < total_g) {
-                const int vi = i / n, li = i - vi * n;                   // consecutive threads -> consecutive rows
-                const int p = t * kTile + list[li];
-                const int y = p / a.W;
-                d[u] = load_vertex(v, b, y, p - y * a.W, vi);
-                row[u] = ((size_t)b * v.K + vi) * a.cap + before + li;
-            }
+            for (int u = 0; u < kKeys; ++u)
+                if (v0 + u < v.K) d[u] = load_vertex(v, b, y, x, v0 + u);
+#pragma unroll
+            for (int u = 0; u < kKeys; ++u)
+                if (v0 + u < v.K) drow[(size_t)(v0 + u) * a.cap] = d[u];
         }
-#pragma unroll
-        for (int u = 0; u < kGather; ++u)
-            if (i0 + u * kBlock < total_g) dirs[row[u]] = d[u];
     }
 }
