@@ -608,6 +608,7 @@ static int finish_v3(const pvv_problem *p, const Layout &L, char *ws, float *d_o
     // MI355X: 2 at B*K = 576, 8 for a single image)
     int nsplit = kRefitSplitMax;
     while (nsplit > 1 && (long long)p->B * p->K * nsplit > 6ll * num_cus()) nsplit >>= 1;
+    nsplit = tuning_int("PVV_REFIT_SPLIT", nsplit);
     // the re-vote's prefilter is the count kernel's second-level test: used where that kernel is valid and the grid is
     // large enough to be VALU-bound (measured: -1.3 % per call at B = 64, +-0 at B = 8, +1.2 % at B = 1)
     const Bf16Consts fc = bf16_consts(p->inlier_thresh);
