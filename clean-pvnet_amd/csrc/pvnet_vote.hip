@@ -439,17 +439,15 @@ void launch_scan(const MaskArgs &m, const Layout &L, char *ws, int B, hipStream_
         hipLaunchKernelGGL((k_tile_scan<ES, false, MODE>), dim3((unsigned)total), dim3(kBlock), 0, st, m, tiles, lists, draws, (int)total);
         return;
     }
-    // persistent over the B*T tiles: as many blocks as the chip holds at once, every block the same number of tiles (+-1)
-    static int per_cu[64] = {0};                                    // resident blocks per CU of this instantiation, per device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!per_cu[dev]) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile_scan<ES, true, MODE>, kBlock, 0) != hipSuccess || n < 1) n = 4;
-        per_cu[dev] = n > 8 ? 8 : n;
-    }
-    const long long resident = (long long)per_cu[dev] * num_cus();
-    const long long per_block = (total + resident - 1) / resident;
+    // ONE tile per block.  Round 2 made this kernel persistent over the resident blocks (8 per CU, every block 4-5 tiles with
+    // the next tile's loads ahead: 4.0 -> 4.4 TB/s on the cold int64 mask) when it issued ~400 instructions per wave and
+    // tile; at ~300 (round 3) the dispatcher's overlap of short blocks wins again -- one-process A/B over 4 ... 80 blocks
+    // per CU in the grid rule, monotone: -2.1 % per call at B = 64, -1.1 % at B = 16, -2.4 % at B = 128, +-0 at B = 1 and
+    // on config 5 against the persistent grid.  (The kernel still walks gridDim-strided tiles with its read-ahead if it is
+    // ever launched with fewer blocks: PVV_SCAN_PER_CU in tuning builds.)
+    const int per_cu_t = tuning_int("PVV_SCAN_PER_CU", 0);
+    long long per_block = 1;
+    if (per_cu_t > 0) per_block = (total + (long long)per_cu_t * num_cus() - 1) / ((long long)per_cu_t * num_cus());
     const int grid = (int)((total + per_block - 1) / per_block);
     hipLaunchKernelGGL((k_tile_scan<ES, true, MODE>), dim3(grid), dim3(kBlock), 0, st, m, tiles, lists, draws, (int)total);
 }
