@@ -69,11 +69,12 @@
 
   Config 4 at B = 32 (sparse masks: nothing to stage; round 2: 0.1016 ms per call) takes {{cfg4_ms}} ms: the first call stages,
   finds every image below 8 chunks, and from then on the stage hint keeps AUTO on the full pass (§4.6).  Host side: one call costs 27–32 µs of host time on an idle stream, so below B ≈ 2 the eager wall clock
-  is host-bound; a captured graph removes that (the replay column).  **Small batches: the floor stays where round 2 left
-  it** (B = 1: 33–35 µs, B = 8: 62–65 µs, default path ≈ 0.93 M images/s; VERDICT r1's targets 20 / 45 µs / 1.5 M are not
-  met).  The path has five dependent phases between the mask and the keypoints and each costs 2.5–5 µs as a launch or
+  is host-bound; a captured graph removes that (the replay column).  **Small batches moved by the width of their phases, not their number**
+  (B = 1: 33–35 → 29–30 µs, B = 8: 62–65 → 60 µs, default path 0.93 → 1.0 M images/s; VERDICT r1's targets 20 / 45 µs / 1.5 M are
+  not met).  The path has five dependent phases between the mask and the keypoints and each costs 2.5–5 µs as a launch or
   inside a fused kernel (§4.4, §4.5: tickets, in-kernel hand-offs, a fully fused back end, up-front loads — twice —, item
-  and grid sweeps were all built and measured); round 3 added nothing below B = 16 and says so.
+  and grid sweeps were all built and measured); what round 3 took out of them is latency INSIDE the phases: the wave
+  reductions on DPP instead of `ds_bpermute` butterflies (§4.3), a leaner mask scan, no stored draws.
 * The reference's own kernel on the same GPU (`oracle/_ref`, `tests/test_ref_pin.py::test_reference_kernel_timed_on_the_same_gpu`):
   `voting_for_hypothesis_kernel` + `torch.sum` for ONE 480×640 image (K = 9, 512 hypotheses, what P:155-159 runs per
   image and round) takes 0.21 ms on the MI355X, i.e. 13 ms for the 64 images whose winners the staged pass finds in
