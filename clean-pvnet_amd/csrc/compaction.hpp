@@ -454,7 +454,10 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
         const int vi = gid / h.hn, hi = gid - vi * h.hn;
         const size_t o = ((size_t)b * v.K + vi) * h.hn + hi;
         h.counts[o] = 0;
-        if (h.lead && hi < 4) h.lead[((size_t)b * v.K + vi) * 8 + 4 + hi] = 0;
+        if (h.lead && hi == 0) {                                  // all four, whatever hn is (hi < min(4, hn) left words unzeroed for hn < 4)
+            int *lw = h.lead + ((size_t)b * v.K + vi) * 8 + 4;
+            lw[0] = 0; lw[1] = 0; lw[2] = 0; lw[3] = 0;
+        }
         if (tn <= 0) {
             h.hyps[o] = make_float2(0.f, 0.f);
             if (h.draws_out) { h.draws_out[2 * o] = -1; h.draws_out[2 * o + 1] = -1; }

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
     int inl[kLead];
     bool lnear[kLead];       // a leader beyond 1e15 px (or non-finite) gets no sure inliers: the exact vote's squares overflow
 #pragma unroll               // out there (norm2 = inf: never an inlier) and this test's do not -- its partial count alone is a bound
-    for (int w = 0; w < kLead; ++w) { inl[w] = 0; lnear[w] = fabsf(ld[w].x) < 1e15f && fabsf(ld[w].y) < 1e15f; }
+    for (int w = 0; w < kLead; ++w) { inl[w] = 0; lnear[w] = lc[w] >= 0 && fabsf(ld[w].x) < 1e15f && fabsf(ld[w].y) < 1e15f; }   // (no leader in the slot: nothing to count)
     for (;;) {
 #pragma unroll
         for (int u = 0; u < kTrip; ++u) {

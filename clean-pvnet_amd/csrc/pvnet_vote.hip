@@ -196,24 +196,38 @@ bool may_stage(const pvv_problem *p)
 // k_finalize_v3 leaves each image's mean winner ratio in a small host-visible array (one per device, pinned, written by
 // the GPU with plain stores), and AUTO stages a call only if the ratios the LAST completed calls left there reach a
 // threshold that depends on the problem's size.  The hint lags by the calls still in flight and mixes calls when several
-// streams or problem shapes interleave; it only ever selects between two exact paths.  No data yet (first call, or first
+// streams interleave (a hint left by another problem SHAPE is ignored); it only ever selects between two exact paths.  No data yet (first call, or first
 // call under stream capture, where no memory can be pinned): stage.  PVV_COUNT_STAGED / PVV_COUNT_FULL ignore it.
 // ---------------------------------------------------------------------------------------------
 struct StageHint {
     float *ratio = nullptr;   // 2 x kMaxBatchLds floats, hipHostMalloc: [b] winner ratio (< -1.5 = never written, -1 = skipped
                               // image), [kMaxBatchLds + b] the image's tn
     int n = 0;                // images of the last call that was given the buffer
+    int shape[5] = {0, 0, 0, 0, 0};   // B, H, W, K, hn of that call: a hint left by another problem shape is ignored
     bool tried = false;
 };
 StageHint g_hint[64];
-std::mutex g_hint_mu;
+std::mutex g_hint_mu;        // guards every field of g_hint[] (the GPU writes only the pinned ratio[] words)
 
-StageHint *stage_hint(hipStream_t st, bool allocate)
+// the device the STREAM belongs to (a caller may launch on a stream of a device that is not current)
+int stream_device(hipStream_t st)
 {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    int dev = -1;
+    if (st) {
+        hipDevice_t d;
+        if (hipStreamGetDevice(st, &d) == hipSuccess) dev = (int)d; else (void)hipGetLastError();
+    }
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev >= 0 && dev < 64 ? dev : -1;
+}
+
+// the device's hint slot, with its pinned array allocated on first use (never while the stream is capturing).  Call with
+// g_hint_mu held.
+StageHint *stage_hint_locked(hipStream_t st, bool allocate)
+{
+    const int dev = stream_device(st);
+    if (dev < 0) return nullptr;
     StageHint *g = &g_hint[dev];
-    std::lock_guard<std::mutex> lock(g_hint_mu);
     if (!g->tried && allocate) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -227,12 +241,33 @@ StageHint *stage_hint(hipStream_t st, bool allocate)
     return g->ratio ? g : nullptr;
 }
 
-// mean winner ratio of the images the last calls reported (< 0: no data) and the largest tn among them
-float stage_hint_mean(hipStream_t st, float *max_tn = nullptr)
+// A v3 call is about to leave its winners' ratios in the device's slot: record whose they are and hand out the array.
+float *stage_hint_claim(const pvv_problem *p, hipStream_t st)
 {
-    StageHint *g = stage_hint(st, false);
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    StageHint *g = stage_hint_locked(st, true);
+    if (!g) return nullptr;
+    const int shape[5] = {p->B, p->H, p->W, p->K, p->hn};
+    if (memcmp(g->shape, shape, sizeof(shape)) != 0) {
+        // another problem shape: what the array holds says nothing about this one -- until this call reports, no data
+        memcpy(g->shape, shape, sizeof(shape));
+        for (int i = 0; i < p->B; ++i) g->ratio[i] = -2.f;
+    }
+    g->n = p->B;
+    return g->ratio;
+}
+
+// mean winner ratio of the images the last calls OF THIS SHAPE reported (< 0: no data) and the largest tn among them
+float stage_hint_mean(const pvv_problem *p, hipStream_t st, float *max_tn = nullptr)
+{
     if (max_tn) *max_tn = -1.f;
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    StageHint *g = stage_hint_locked(st, false);
     if (!g || g->n <= 0) return -1.f;
+    if (p) {
+        const int shape[5] = {p->B, p->H, p->W, p->K, p->hn};
+        if (memcmp(g->shape, shape, sizeof(shape)) != 0) return -1.f;
+    }
     double sum = 0;
     int cnt = 0;
     float mt = 0.f;
@@ -259,7 +294,7 @@ bool stage_hint_allows(const pvv_problem *p, hipStream_t st)
 {
     if (p->count_kernel != PVV_COUNT_AUTO) return true;
     float max_tn = -1.f;
-    const float m = stage_hint_mean(st, &max_tn);
+    const float m = stage_hint_mean(p, st, &max_tn);
     if (m < 0.f) return true;
     // (images of fewer than kStageMinChunks chunks are counted completely by the first launch: when the last calls held
     // no larger one -- config 4's sparse masks -- the two later launches would only be launched to leave again)
@@ -576,7 +611,7 @@ PVV_EXPORT const char *pvv_last_error(void) { return g_err; }
 
 PVV_EXPORT int pvv_stage_hint_query(float *mean_ratio, float *threshold, const pvv_problem *p, void *stream)
 {
-    const float m = stage_hint_mean((hipStream_t)stream);
+    const float m = stage_hint_mean(p, (hipStream_t)stream);
     if (mean_ratio) *mean_ratio = m;
     if (threshold) *threshold = p ? stage_hint_threshold(p) : -1.f;
     return m >= 0.f ? 1 : 0;
@@ -621,11 +656,10 @@ static int finish_v3(const pvv_problem *p, const Layout &L, char *ws, float *d_o
     if (band) launch_refit(k_select_refit<true>); else launch_refit(k_select_refit<false>);
     if (int e = check_launch("k_select_refit")) return e;
     if (int e = mark(p, PVV_MARK_SELECT, st)) return e;
-    StageHint *hint = stage_hint(st, true);
-    if (hint) hint->n = p->B;
+    float *hint = stage_hint_claim(p, st);
     hipLaunchKernelGGL(k_finalize_v3, dim3(p->B), dim3(64), 0, st, (const int *)(ws + L.tn),
                        (const double *)(ws + L.sums), (float2 *)d_out, p->K, p->singular_policy, nsplit,
-                       (const float *)(ws + L.ratio), hint ? hint->ratio : nullptr, kMaxBatchLds);
+                       (const float *)(ws + L.ratio), hint, kMaxBatchLds);
     if (int e = check_launch("k_finalize_v3")) return e;
     return mark(p, PVV_MARK_END, st);
 }
@@ -732,12 +766,13 @@ PVV_EXPORT int pvv_decode_keypoint_un_pnp(const pvv_problem *p, int32_t hn_est, 
 PVV_EXPORT int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace, size_t workspace_bytes,
                                       int zero_counts, void *stream)
 {
-    // The count pass of a v3 call: staged when the call itself was -- but only with cleared counters: the elimination
-    // compares PARTIAL counts, stale totals would change which hypotheses survive.  zero_counts = 0 therefore re-runs the
-    // FULL kernel (what it always did), and is refused when the caller explicitly asked for PVV_COUNT_STAGED.
+    // Re-runs the count pass on the state a previous call left in the workspace.  That call may have been the estimate or
+    // the fused un_pnp pass, which need EVERY count: so the pass is re-run in stages only when the caller says so
+    // explicitly (PVV_COUNT_STAGED -- the state must then be a v3 call's), never under AUTO.  A staged pass
+    // compares PARTIAL counts and therefore needs cleared counters.
     if (p && p->count_kernel == PVV_COUNT_STAGED && !zero_counts)
         return fail(PVV_E_ARG, "a staged count pass needs zero_counts = 1");
-    const bool v3 = zero_counts != 0;
+    const bool v3 = p && p->count_kernel == PVV_COUNT_STAGED;
     if (int e = validate(p)) return e;
     if (!d_workspace) return fail(PVV_E_ARG, "workspace is NULL");
     Layout L = make_layout(p);

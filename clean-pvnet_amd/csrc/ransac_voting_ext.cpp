@@ -429,18 +429,37 @@ std::vector<double> count_kernel_ms_in_pipeline(std::vector<at::Tensor> masks, s
 std::vector<std::vector<double>> stage_ms_in_pipeline(std::vector<at::Tensor> masks, std::vector<at::Tensor> vertices,
                                                       int64_t round_hyp_num, double inlier_thresh, int64_t min_num,
                                                       int64_t max_num, int64_t seed, int64_t reps, int64_t count_kernel,
-                                                      bool inner_marks, bool estimate)
+                                                      bool inner_marks, bool estimate, std::vector<at::Tensor> segs)
 {
-    TORCH_CHECK(!masks.empty() && masks.size() == vertices.size(), "need as many masks as vertex fields");
+    // segs (optional, one [b,c,h,w] float32 tensor per vertex field): time pvv_decode_keypoint_v3 -- the class argmax fused
+    // into the mask scan, the int64 mask written out -- instead of pvv_ransac_voting_v3; `masks` may then be empty
+    const bool fused = !segs.empty();
+    TORCH_CHECK(!vertices.empty() && (fused ? segs.size() == vertices.size() : masks.size() == vertices.size()),
+                "need as many masks (or segs) as vertex fields");
+    TORCH_CHECK(!(fused && estimate), "segs and estimate are exclusive");
     const c10::DeviceGuard device_guard(vertices[0].device());
     std::vector<hipEvent_t> ev((size_t)PVV_N_MARKS * (size_t)reps);
     for (auto &e : ev) TORCH_CHECK(hipEventCreate(&e) == hipSuccess, "hipEventCreate failed");
     std::vector<at::Tensor> keep;
     for (int64_t r = 0; r < reps; ++r) {
-        const at::Tensor &mask = masks[r % masks.size()], &vertex = vertices[r % masks.size()];
+        const at::Tensor &vertex = vertices[r % vertices.size()];
+        at::Tensor mask;
+        if (fused) {
+            const at::Tensor &seg = segs[r % segs.size()];
+            TORCH_CHECK(seg.is_cuda() && seg.scalar_type() == at::kFloat && seg.dim() == 4 && seg.size(0) == vertex.size(0) &&
+                            seg.size(2) == vertex.size(1) && seg.size(3) == vertex.size(2), "seg must be float32 [b,c,h,w] matching vertex");
+            mask = at::empty({seg.size(0), seg.size(2), seg.size(3)}, seg.options().dtype(at::kLong));
+        } else {
+            mask = masks[r % masks.size()];
+        }
         pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, PVV_SINGULAR_REFERENCE,
                                      seed + r);
         p.count_kernel = (int32_t)count_kernel;
+        if (fused) {
+            const at::Tensor &seg = segs[r % segs.size()];
+            p.seg_classes = (int32_t)seg.size(1);
+            for (int i = 0; i < 4; ++i) p.seg_stride[i] = seg.stride(i);
+        }
         std::vector<void *> marks(PVV_N_MARKS);
         for (int i = 0; i < PVV_N_MARKS; ++i) marks[(size_t)i] = (void *)ev[(size_t)PVV_N_MARKS * (size_t)r + (size_t)i];
         // inner_marks = false: no records INSIDE the count pass (each costs ~2 us): its duration is then what rocprofv3 sees
@@ -456,6 +475,12 @@ std::vector<std::vector<double>> stage_ms_in_pipeline(std::vector<at::Tensor> ma
                                                 nullptr, cur_stream(vertex)),
                "estimate_voting_distribution");
             keep.push_back(cov);
+        } else if (fused) {
+            ok(pvv_decode_keypoint_v3(&p, segs[r % segs.size()].data_ptr<float>(), vertex.data_ptr<float>(), nullptr, nullptr, ws.data_ptr(),
+                                      (size_t)ws.numel(), mask.data_ptr<int64_t>(), out.data_ptr<float>(), nullptr, nullptr,
+                                      cur_stream(vertex)),
+               "decode_keypoint_v3");
+            keep.push_back(mask);
         } else {
             ok(pvv_ransac_voting_v3(&p, mask.data_ptr(), vertex.data_ptr<float>(), nullptr, nullptr, ws.data_ptr(),
                                     (size_t)ws.numel(), out.data_ptr<float>(), nullptr, nullptr, cur_stream(vertex)),
@@ -500,11 +525,16 @@ void stream_read_probe(at::Tensor buf, at::Tensor sink)
 // Re-run only the inlier-count kernel on the state a previous ransac_voting_v3 call left in `ws`
 // (bench.py brackets this with HIP events to get the dominant kernel's duration).
 void rerun_count_kernel(at::Tensor mask, at::Tensor vertex, int64_t hn, double inlier_thresh, int64_t min_num,
-                        int64_t max_num, at::Tensor ws, bool zero_counts, int64_t count_kernel)
+                        int64_t max_num, at::Tensor ws, bool zero_counts, int64_t count_kernel, std::optional<int64_t> cap)
 {
     const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     pvv_problem p = make_problem(mask, vertex, hn, inlier_thresh, min_num, max_num, 0, 0);
     p.count_kernel = (int32_t)count_kernel;
+    // the workspace offsets depend on cap: a workspace made with ransac_voting_v3(..., cap=) needs the same value here
+    if (cap.has_value()) {
+        TORCH_CHECK(*cap >= 1 && *cap <= (int64_t)p.H * p.W, "cap must be in [1, H*W]");
+        p.cap = (int32_t)*cap;
+    }
     check_dev(ws, "workspace", at::kByte);
     ok(pvv_rerun_count_kernel(&p, ws.data_ptr(), (size_t)ws.numel(), zero_counts ? 1 : 0, cur_stream(vertex)),
        "rerun_count_kernel");
@@ -545,11 +575,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("selection"), py::arg("seed"), py::arg("want_hyp"), py::arg("first_image") = 0, py::arg("count_kernel") = 0);
     m.def("rerun_count_kernel", &rerun_count_kernel, "re-launch the inlier-count pass (profiling aid)", py::arg("mask"),
           py::arg("vertex"), py::arg("hn"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"), py::arg("ws"),
-          py::arg("zero_counts"), py::arg("count_kernel") = 0);
+          py::arg("zero_counts"), py::arg("count_kernel") = 0, py::arg("cap") = py::none());
     m.def("stage_ms_in_pipeline", &stage_ms_in_pipeline,
           "per-stage durations inside full v3 calls, HIP events at the stage boundaries (profiling aid)", py::arg("masks"),
           py::arg("vertices"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"),
-          py::arg("seed"), py::arg("reps"), py::arg("count_kernel") = 0, py::arg("inner_marks") = true, py::arg("estimate") = false);
+          py::arg("seed"), py::arg("reps"), py::arg("count_kernel") = 0, py::arg("inner_marks") = true, py::arg("estimate") = false,
+          py::arg("segs") = std::vector<at::Tensor>());
     m.def("stage_hint", [](at::Tensor mask, at::Tensor vertex, int64_t hn) {
               pvv_problem p = make_problem(mask, vertex, hn, 0.99, 5, 30000, 0, 0);
               float mean = -1.f, thr = -1.f;

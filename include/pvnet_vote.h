@@ -277,11 +277,13 @@ int pvv_stage_hint_query(float *mean_ratio, float *threshold, const pvv_problem 
  * layer call recorded in `d_workspace` (same problem), so its duration can be
  * bracketed with HIP events on `stream`.  zero_counts != 0 first clears the
  * counters (a separate memset node) so the result stays valid; with 0 nothing
- * but the kernel is enqueued and the counters keep accumulating.  When the
- * problem counts in stages (see PVV_COUNT_STAGED) and zero_counts is 1, the
- * whole pass is re-run -- both launches and k_lead; with zero_counts = 0 the
- * FULL kernel runs (the elimination compares partial counts, so it needs
- * cleared counters), and an explicit PVV_COUNT_STAGED is refused then. */
+ * but the kernel is enqueued and the counters keep accumulating.  The pass is
+ * re-run IN STAGES (both launches and k_lead) only when count_kernel is
+ * PVV_COUNT_STAGED explicitly -- the workspace must then hold a v3 call's
+ * state and zero_counts must be 1 (the elimination compares partial counts);
+ * under AUTO the full kernel runs: the workspace may be the estimate's or the
+ * fused un_pnp pass's, which need every count.  `p` must describe the call
+ * that filled the workspace INCLUDING `cap` (the offsets depend on it). */
 int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace,
                            size_t workspace_bytes, int zero_counts,
                            void *stream);

@@ -36,7 +36,58 @@ ROWS = [
     ("cfg5_B2_shard_of_8gpu", "cfg5", 2, {}),
     ("default_path_hn128_maxnum100_B64", "cfg3", 64, {"hn": 128, "max_num": 100}),
     ("default_path_hn128_maxnum100_B1", "cfg3", 1, {"hn": 128, "max_num": 100}),
+    # the layout the REAL caller passes (resnet18.py:66-69,93-94): seg logits and the vertex field are channel
+    # slices of ONE [B, 2+2K, H, W] network output -- the vertex a strided planar view, the mask an argmax away
+    ("cfg3_B64_planar_vertex", "cfg3", 64, {"planar": True}),                 # int64 mask given, planar vertex
+    ("cfg3_B64_decode_fused", "cfg3", 64, {"seg": True}),                     # decode_keypoint_v3: argmax inside the scan
+    ("cfg3_B64_decode_unfused", "cfg3", 64, {"seg": True, "unfused": True}),  # torch.argmax + v3, as resnet18.py:69-71 runs it
+    ("cfg2_B1_decode_fused", "cfg2", 1, {"seg": True}),
+    ("cfg2_B1_decode_unfused", "cfg2", 1, {"seg": True, "unfused": True}),
 ]
+
+
+def make_case(name, dev):
+    """-> dict(call, data, stage(inner) -> rows of stage_ms_in_pipeline, B, H, W, K, hn, max_num) of one row."""
+    import lib
+    lib._register_clean_pvnet_amd()
+    from clean_pvnet_amd import ransac_voting as ext
+    from clean_pvnet_amd import synth
+    from lib.csrc.ransac_voting.ransac_voting_gpu import ransac_voting_layer_v3
+    _n, cfgname, B, over = [r for r in ROWS if r[0] == name][0]
+    cfg = dict(synth.CONFIGS[cfgname])
+    H, W, K = cfg["H"], cfg["W"], cfg["K"]
+    hn = over.get("hn", cfg["hn"])
+    max_num = over.get("max_num", 30000)
+    gen = {k: v for k, v in cfg.items() if k not in ("B", "hn")}
+    if "fg" in over:
+        gen["fg"] = over["fg"]
+    d = synth.make_batch(B=B, **gen, device=dev, planar=bool(over.get("planar") or over.get("seg")))
+    mask, vertex = d["mask"], d["vertex"]
+    case = dict(B=B, H=H, W=W, K=K, hn=hn, max_num=max_num, data=d, layout="contiguous [B,H,W,K,2] vertex, int64 mask")
+    if over.get("seg"):
+        x = torch.empty(B, 2 + 2 * K, H, W, device=dev)
+        x[:, :2] = torch.randn(B, 2, H, W, device=dev) * 0.1
+        x[:, 0] += 3.0 * (mask == 0)
+        x[:, 1] += 3.0 * (mask != 0)
+        x[:, 2:] = vertex.permute(0, 3, 4, 1, 2).reshape(B, 2 * K, H, W)
+        seg, ver = x[:, :2], x[:, 2:]
+        vtx = ver.permute(0, 2, 3, 1).view(B, H, W, K, 2)
+        case["layout"] = "seg logits + planar vertex: channel slices of one [B,2+2K,H,W] tensor (resnet18.py:93-94)"
+        if over.get("unfused"):
+            case["call"] = lambda: ransac_voting_layer_v3(torch.argmax(seg, 1), vtx, hn, inlier_thresh=0.99, max_num=max_num)
+            case["stage"] = lambda inner, reps=36: ext.stage_ms_in_pipeline([torch.argmax(seg, 1)], [vtx], hn, 0.99, 5, max_num, 1, reps, ext.COUNT_AUTO, inner)
+        else:
+            case["call"] = lambda: ext.decode_keypoint_v3(seg, vtx, hn, 0.99, 5, max_num, None, None, 7, ext.SINGULAR_REFERENCE)[0]
+            case["stage"] = lambda inner, reps=36: ext.stage_ms_in_pipeline([], [vtx], hn, 0.99, 5, max_num, 1, reps, ext.COUNT_AUTO, inner, False, [seg])
+        case["tn"] = lambda: ext.decode_keypoint_v3(seg, vtx, hn, 0.99, 5, max_num, None, None, 7, ext.SINGULAR_REFERENCE)[3]
+        case["keep"] = x
+    else:
+        if over.get("planar"):
+            case["layout"] = "planar vertex (storage [B,2K,H,W], the view resnet18.py:66-68 makes), int64 mask"
+        case["call"] = lambda: ransac_voting_layer_v3(mask, vertex, hn, inlier_thresh=0.99, max_num=max_num)
+        case["stage"] = lambda inner, reps=36: ext.stage_ms_in_pipeline([mask], [vertex], hn, 0.99, 5, max_num, 1, reps, ext.COUNT_AUTO, inner)
+        case["tn"] = lambda: ext.ransac_voting_v3(mask, vertex, hn, 0.99, 5, max_num, None, None, 1, ext.SINGULAR_REFERENCE)[2]
+    return case
 
 
 def pct(v, q):
@@ -61,19 +112,10 @@ def main():
     for name, cfgname, B, over in ROWS:
         if want and name not in want:
             continue
-        cfg = dict(synth.CONFIGS[cfgname])
-        H, W, K = cfg["H"], cfg["W"], cfg["K"]
-        hn = over.get("hn", cfg["hn"])
-        max_num = over.get("max_num", 30000)
-        gen = {k: v for k, v in cfg.items() if k not in ("B", "hn")}
-        if "fg" in over:
-            gen["fg"] = over["fg"]
-        d = synth.make_batch(B=B, **gen, device=dev)
-        mask, vertex = d["mask"], d["vertex"]
+        case = make_case(name, dev)
+        H, W, K, hn, max_num, d = case["H"], case["W"], case["K"], case["hn"], case["max_num"], case["data"]
+        call = case["call"]
         n = args.calls if B <= 16 else max(20, args.calls // 4)
-
-        def call():
-            return ransac_voting_layer_v3(mask, vertex, hn, inlier_thresh=0.99, max_num=max_num)
 
         for _ in range(10):
             out = call()
@@ -128,11 +170,11 @@ def main():
         # (e) the kernels as they run inside the calls: HIP events at the stage boundaries (pvv_problem.ev_marks).  The count
         #     pass = one k_count_bf16 launch, or -- staged (AUTO on large batches) -- k_count_bf16<first> + k_lead +
         #     k_count_bf16<filter>
-        _o, win, tn, ws = ext.ransac_voting_v3(mask, vertex, hn, 0.99, 5, max_num, None, None, 1, ext.SINGULAR_REFERENCE)
+        tn = case["tn"]()
         stage_names = ("k_tile_scan", "k_compact_hyp", "count_pass", "k_select_refit", "k_finalize_v3", "count_first_launch", "k_lead")
         stages = {}
         for inner in (False, True):        # the pass without records inside it; then its split
-            st = ext.stage_ms_in_pipeline([mask], [vertex], hn, 0.99, 5, max_num, 1, 36, ext.COUNT_AUTO, inner)[6:]
+            st = case["stage"](inner)[6:]
             for j, nm in enumerate(stage_names):
                 if (j >= 5) == inner and pct([r[j] for r in st], 0.5) >= 0:
                     stages[nm] = round(pct([r[j] for r in st], 0.5), 4)
@@ -141,7 +183,7 @@ def main():
         evals = tn_sum * K * hn
         alg = synth.dense_field_bytes(B, H, W, K, hn)
         err = float((out - d["kpt_2d"]).abs().max())
-        row = {"B": B, "H": H, "W": W, "K": K, "hn": hn, "max_num": max_num, "tn_mean": round(tn_sum / B, 1),
+        row = {"B": B, "H": H, "W": W, "K": K, "hn": hn, "max_num": max_num, "layout": case["layout"], "tn_mean": round(tn_sum / B, 1),
                "calls": n,
                "wall_ms_per_call": round(1e3 * wall / n, 4), "images_per_s_wall": round(B * n / wall, 1),
                "host_enqueue_ms_per_call_backlogged": round(1e3 * t_enq / n, 4),
@@ -156,7 +198,7 @@ def main():
                "known_answer_max_err_px": round(err, 3)}
         res["rows"][name] = row
         print(name, json.dumps(row), flush=True)
-        del d, mask, vertex, ws
+        del d, case, call
         torch.cuda.empty_cache()
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
