@@ -57,12 +57,13 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy reaches
-# VALU issue: 1024 SIMDs; a wave64 VALU instruction occupies its SIMD for CYCLES_PER_VALU_MEASURED cycles as measured on
-# this chip with true cycle counters (tools/microbench/valu_rate3.hip under rocprofv3 --pmc, profiles/r04_microbench.txt:
-# v_fma / v_mul / v_cmp / v_alignbit / v_min3 ~4 cycles, v_add / v_sub ~2); MI355X_MICROARCH.md's table quotes 2 cycles
-# for v_fma_f32 (the figure the 157 TF vector peak needs WITHOUT packed math) -- both ceilings are reported.
+# VALU issue: 1024 SIMDs; a wave64 VALU instruction occupies its SIMD for 2 cycles at full rate (MI355X_MICROARCH.md's
+# table; confirmed in round 4 with true shader-clock counts, tools/microbench/valu_rate3.hip -> profiles/r04_microbench.txt:
+# v_fma / v_mul / v_add / v_sub 1.3-2.1 cycles at 8 waves per SIMD, 2.4-2.9 at 4; v_alignbit / v_min3 / v_cmp / v_pk_fma are
+# half rate, 2.6-4.3.  Round 1's "4.2 cycles" divided event times by an ASSUMED 2.4 GHz while the chip ran the all-FMA
+# test at ~1.55 GHz, and used too few waves).  The ceiling below is the full-rate one at the device's max clock.
 # VALU_PER_TILE: one 16-pixel x 32-hypothesis matrix-core tile (512 evaluations) costs 21 VALU in the steady-state loop.
-VALU_PER_TILE, CYCLES_PER_VALU, CYCLES_PER_VALU_GUIDE, N_SIMD, EVALS_PER_TILE = 21, 4.0, 2.0, 1024, 512
+VALU_PER_TILE, CYCLES_PER_VALU, N_SIMD, EVALS_PER_TILE = 21, 2.0, 1024, 512
 
 
 def load_profile(name):
@@ -519,26 +520,25 @@ def main():
                     blk["traffic_GBs"] = round(t / (blk["ms_avg"] * 1e-3) / 1e9, 1)
                     blk["traffic_source"] = pmc_src
         # ---- the count pass against fp32 VALU issue, on ISSUED instructions: SQ_INSTS_VALU of the pass's
-        # kernels (static, per launch) / the pass's duration inside calls (live) against 1024 SIMDs x max clock / cycles per
-        # wave64 VALU instruction.  `frac` uses the MEASURED occupancy of a SIMD per instruction (4 cycles: true-cycle
-        # microbenchmark, see the constants above); `frac_vs_guide_2cyc` the guide's table value.  `valu_busy` is the counter
-        # figure proper: SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs), per kernel of the pass.
+        # kernels (static, per launch) / the pass's duration inside calls (live) against 1024 SIMDs x max clock / 2 cycles
+        # per wave64 VALU instruction (full rate).  `busy_frac` is the counter figure proper -- the share of the pass's SIMD
+        # cycles in which a VALU instruction was executing: sum_k SQ_ACTIVE_INST_VALU_k x 4 / 1024 SIMDs over
+        # sum_k GRBM_GUI_ACTIVE_k / 8 XCDs -- which also sees the half-rate instructions of the loop (v_alignbit, v_min3,
+        # v_cmp: ~4 cycles) and the clock the chip really ran at.
         clock_ghz = torch.cuda.get_device_properties(dev).clock_rate / 1e6 if hasattr(torch.cuda.get_device_properties(dev), "clock_rate") else 2.4
         issued = pmc_sum(pass_names, "SQ_INSTS_VALU")
+        act, gui = pmc_sum(pass_names, "SQ_ACTIVE_INST_VALU"), pmc_sum(pass_names, "GRBM_GUI_ACTIVE")
         peak_issue = N_SIMD * clock_ghz * 1e9 / CYCLES_PER_VALU
         roofline_valu = {"bound": "valu_issue", "kernel": " + ".join(pass_names), "ms_avg": round(k_avg_ms, 4), "unit": "T wave-instructions/s",
                          "issued_valu_wave_instructions": issued,
                          "achieved": round(issued / (k_avg_ms * 1e-3) / 1e12, 4) if issued and k_avg_ms else None,
                          "peak": round(peak_issue / 1e12, 4),
                          "frac": round(issued / (k_avg_ms * 1e-3) / peak_issue, 4) if issued and k_avg_ms else None,
-                         "frac_vs_guide_2cyc": round(issued / (k_avg_ms * 1e-3) / (peak_issue * CYCLES_PER_VALU / CYCLES_PER_VALU_GUIDE), 4) if issued and k_avg_ms else None,
-                         "valu_busy_from_counters": ({n: call_pmc["kernels"][n].get("valu_busy") for n in pass_names} if call_pmc and issued else None),
-                         "evaluations_of_a_full_pass": evals,
-                         "evaluations_executed": (int(call_pmc.get("mfma_tiles_per_pass", 0)) * EVALS_PER_TILE or None) if call_pmc else None,
-                         "source": pmc_src,
-                         "model": "%d SIMDs x %.2f GHz (device max clock) / %.1f cycles per wave64 VALU instruction (measured with cycle "
-                                  "counters; MI355X_MICROARCH.md's table says %.0f): issued instructions, whatever they compute -- prologues, "
-                                  "spill traffic and flagged tiles included" % (N_SIMD, clock_ghz, CYCLES_PER_VALU, CYCLES_PER_VALU_GUIDE)}
+                         "busy_frac": round(act * 4 / N_SIMD / (gui / 8), 4) if act and gui else None,
+                         "busy_frac_per_kernel": ({n: call_pmc["kernels"][n].get("valu_busy") for n in pass_names} if call_pmc and issued else None),
+                         "evaluations_of_a_full_pass": evals, "source": pmc_src,
+                         "model": "%d SIMDs x %.2f GHz (device max clock) / %.0f cycles per wave64 VALU instruction: ISSUED instructions, "
+                                  "whatever they compute -- prologues, spill traffic and flagged tiles included" % (N_SIMD, clock_ghz, CYCLES_PER_VALU)}
 
         extra = {"tn_mean": round(float(tn_cpu.float().mean()), 1) if tn_cpu.numel() else 0.0,
                  "known_answer_max_err_px": round(err, 3),
@@ -671,9 +671,10 @@ def un_pnp_leg(data, out, ext, ransac_voting_layer_v3, estimate_voting_distribut
         "T_evaluations_per_s": round(evals_e / (est_ms * 1e-3) / 1e12, 3),
         "loop_only_valu_frac": round(tiles * VALU_PER_TILE / (est_ms * 1e-3) / peak_issue, 4),
         "issued_valu_wave_instructions": issued, "issued_valu_frac": round(issued / (est_ms * 1e-3) / peak_issue, 4) if issued else None,
-        "valu_busy_from_counters": est_pmc.get("valu_busy"),
-        "model": "loop_only: %d VALU per 512-evaluation matrix-core tile x tiles / time against 1024 SIMDs x %.2f GHz / %.1f cycles; "
-                 "issued: SQ_INSTS_VALU (static, profiles/call_pmc.json) / time against the same ceiling" % (VALU_PER_TILE, clock_ghz, CYCLES_PER_VALU),
+        "busy_frac_from_counters": est_pmc.get("valu_busy"),
+        "model": "loop_only: %d VALU per 512-evaluation matrix-core tile x tiles / time against 1024 SIMDs x %.2f GHz / %.0f cycles "
+                 "(full rate; the loop's v_alignbit / v_min3 / v_cmp are half rate); issued: SQ_INSTS_VALU (static, "
+                 "profiles/call_pmc.json) / time against the same ceiling" % (VALU_PER_TILE, clock_ghz, CYCLES_PER_VALU),
         "scan_ms": round(med(0), 4), "compact_hyp_ms": round(med(1), 4), "covariance_ms": round(med(3), 4)}
     return res
 

@@ -218,6 +218,126 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(MaskArgs a, uint32_t *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The mask scan of decode_keypoint for a TWO-CLASS seg (PVNet's seg_dim; resnet18.py:69 `torch.argmax(output['seg'], 1)`):
+// the layout the real caller passes is two contiguous float32 planes per image (channel slices of the network's output
+// tensor, resnet18.py:93).  One tile per block; a thread owns 2 x 4 CONSECUTIVE pixels and reads each plane with two
+// 16-byte non-temporal loads (all four in flight at once: the kernel is a read-once stream), decides idx = 1 iff
+// v1 > v0 or (v1 is NaN and v0 is not) -- torch.argmax's first-maximum / NaN rule for two classes -- and ranks its
+// foreground pixels with a wave prefix sum of the per-thread counts (DPP) instead of eight ballots: 8 segments per tile
+// instead of 32.  For two classes the weight of a foreground pixel is 1 in both modes (idx & 0xFF = 1; idx == 1).
+// WRITE_MASK: also store the int64 mask here (two 16-byte stores per 4 pixels).  The host defers that store to
+// k_mask_from_lists on a side stream whenever the tile lists stay complete (no k_tile_subsample): 8 B per pixel written
+// behind a 8 B per pixel read would double the traffic of this kernel (70 us instead of 27 at B = 64).
+// Needs: gw == 1, gh == W, H*W % 4 == 0, the planes 16-byte aligned (host: seg2_ok).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef long long i64x2 __attribute__((ext_vector_type(2)));
+
+template <bool WRITE_MASK>
+__global__ __launch_bounds__(kBlock) void k_tile_scan_seg2(MaskArgs a, uint32_t *__restrict__ tiles,
+                                                           unsigned short *__restrict__ tile_list,
+                                                           float *__restrict__ tile_draw)
+{
+    __shared__ int seg[8];                                         // (half, wave) counts
+    const int g = blockIdx.x;
+    const int b = g / a.T, t = g - b * a.T;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const float *p0 = a.seg + (int64_t)b * a.gb + (int64_t)t * kTile + 4 * threadIdx.x;
+    const float *p1 = p0 + a.gc;
+    constexpr int kHalf = kTile / 2;                               // 1024 pixels = 256 threads x 4
+    f32x4 v0[2], v1[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const bool in = t * kTile + s * kHalf + 4 * (int)threadIdx.x < a.HW;   // HW % 4 == 0: a vector is inside or outside
+        v0[s] = in ? __builtin_nontemporal_load((const f32x4 *)(p0 + s * kHalf)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v1[s] = in ? __builtin_nontemporal_load((const f32x4 *)(p1 + s * kHalf)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    unsigned m4[2];
+    int excl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        unsigned m = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x0 = v0[s][j], x1 = v1[s][j];
+            m |= ((x1 > x0) || (x1 != x1 && x0 == x0)) ? (1u << j) : 0u;
+        }
+        m4[s] = m;
+        const int c = __popc(m);
+        const int inc = wave_incl_scan(c);
+        excl[s] = inc - c;
+        if (lane == 63) seg[s * 4 + wave] = inc;
+    }
+    __syncthreads();
+    int cnt[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cnt[i] = seg[i];
+    int nz = 0, base[2] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i < wave) base[0] += cnt[i];
+        if (i < 4 + wave) base[1] += cnt[i];
+        nz += cnt[i];
+    }
+    if (threadIdx.x == 0) tiles[g] = (uint32_t)nz | ((uint32_t)nz << 12);
+    if (WRITE_MASK && a.mask_out) {
+        long long *mo = a.mask_out + (int64_t)b * a.HW + (int64_t)t * kTile + 4 * threadIdx.x;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (t * kTile + s * kHalf + 4 * (int)threadIdx.x < a.HW) {
+                __builtin_nontemporal_store(i64x2{(long long)(m4[s] & 1u), (long long)((m4[s] >> 1) & 1u)}, (i64x2 *)(mo + s * kHalf));
+                __builtin_nontemporal_store(i64x2{(long long)((m4[s] >> 2) & 1u), (long long)((m4[s] >> 3) & 1u)}, (i64x2 *)(mo + s * kHalf + 2));
+            }
+    }
+    if (nz == 0) return;                                           // (block-uniform: four tiles in five hold no foreground)
+    unsigned short *list = tile_list + (size_t)g * kTile;
+    float *draw = tile_draw + (size_t)g * kTile;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        int r = base[s] + excl[s];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((m4[s] >> j) & 1u) {
+                const int off = s * kHalf + 4 * (int)threadIdx.x + j;
+                list[r] = (unsigned short)off;
+                if (a.want_draws) draw[r] = selection_draw(a, b, t * kTile + off);
+                ++r;
+            }
+    }
+}
+
+// The int64 mask of decode_keypoint from the tile lists (two-class seg: mask = 1 exactly on the listed pixels), when
+// k_tile_scan_seg2 did not write it: launched on the library's side stream right behind the scan, it streams its 8 B per
+// pixel beside the compaction and the VALU-bound count pass instead of in front of them.  One tile per block; a store
+// instruction covers 4 KB contiguous.
+__global__ __launch_bounds__(kBlock) void k_mask_from_lists(const uint32_t *__restrict__ tiles, const unsigned short *__restrict__ tile_list,
+                                                            long long *__restrict__ mask_out, int T, int HW)
+{
+    __shared__ unsigned bm[kTile / 32];
+    const int g = blockIdx.x;
+    const int b = g / T, t = g - b * T;
+    const int nz = (int)(tiles[g] & kTileNzMask);
+    if (nz) {                                                      // (block-uniform)
+        if (threadIdx.x < kTile / 32) bm[threadIdx.x] = 0u;
+        __syncthreads();
+        const unsigned short *list = tile_list + (size_t)g * kTile;
+        for (int e = threadIdx.x; e < nz; e += kBlock) {
+            const unsigned off = list[e];
+            atomicOr(&bm[off >> 5], 1u << (off & 31u));
+        }
+        __syncthreads();
+    }
+    long long *dst = mask_out + (int64_t)b * HW + (int64_t)t * kTile;
+#pragma unroll
+    for (int j = 0; j < kTile / (2 * kBlock); ++j) {
+        const int px = (j * kBlock + (int)threadIdx.x) * 2;        // HW % 4 == 0: a pair is inside or outside
+        if (t * kTile + px >= HW) break;
+        const unsigned w = nz ? bm[px >> 5] >> (px & 31) : 0u;
+        __builtin_nontemporal_store(i64x2{(long long)(w & 1u), (long long)((w >> 1) & 1u)}, (i64x2 *)(dst + px));
+    }
+}
+
 // foreground_num of P:126 / P:208 (sum of the weights) and the number of foreground pixels of image b.
 struct ImageTotals { long long fg; int total; int before; };
 

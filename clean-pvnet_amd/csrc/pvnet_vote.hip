@@ -492,6 +492,8 @@ struct Front {
     VertexArgs v;
     HypArgs h;
     bool can_subsample;
+    bool seg2;                // two-class seg in two contiguous planes: k_tile_scan_seg2 (16-byte loads)
+    long long *mask_deferred; // != nullptr: the scan does not write the int64 mask; k_mask_from_lists does, on the side stream
 };
 
 // stream_first / stream_rest: RNG stream of the hypotheses [0, hn_first) / [hn_first, hn) -- 1 for
@@ -527,6 +529,16 @@ Front make_front(const pvv_problem *p, int mode, const void *d_mask, const float
     const long long max_weight = mode == 1 ? 1 : (d_seg ? (p->seg_classes > 1 ? p->seg_classes - 1 : 1) : 255);
     f.can_subsample = (long long)p->max_num < max_weight * (long long)p->H * p->W;
     m.want_draws = (f.can_subsample && !m.fuse_sub) ? 1 : 0;     // fused subsampling evaluates its draws on demand (compaction.hpp)
+    // decode_keypoint's real layout (resnet18.py:69,93): a two-class seg in two contiguous float32 planes
+    f.seg2 = d_seg && p->seg_classes == 2 && m.gw == 1 && m.gh == p->W && (((long long)p->H * p->W) & 3) == 0 && (m.gb & 3) == 0 &&
+             (m.gc & 3) == 0 && ((uintptr_t)d_seg & 15) == 0;
+    // ... whose int64 mask (8 B per pixel, as much as the scan reads) can be written from the tile lists beside the rest of
+    // the call instead of by the scan, when the lists stay complete (k_tile_subsample would rewrite them) and the batch is
+    // large enough for the two cross-stream events to pay (measured: B = 64 480x640, scan 70.5 -> ~27 us)
+    f.mask_deferred = nullptr;
+    if (f.seg2 && d_mask_out && !(f.can_subsample && !m.fuse_sub) && (long long)p->B * p->H * p->W >= (1ll << 21) &&
+        ((uintptr_t)d_mask_out & 15) == 0)
+        f.mask_deferred = (long long *)d_mask_out;
     VertexArgs &v = f.v;
     v.vertex = d_vertex;
     v.sb = p->vertex_stride[0]; v.sh = p->vertex_stride[1]; v.sw = p->vertex_stride[2];
@@ -547,8 +559,19 @@ Front make_front(const pvv_problem *p, int mode, const void *d_mask, const float
     return f;
 }
 
-int run_scan(const pvv_problem *p, const Front &f, char *ws, const Layout &L, hipStream_t st)
+int run_scan(const pvv_problem *p, const Front &f, char *ws, const Layout &L, hipStream_t st, bool write_mask)
 {
+    if (f.seg2) {
+        MaskArgs m = f.m;
+        if (!write_mask) m.mask_out = nullptr;
+        const unsigned total = (unsigned)((long long)L.T * p->B);
+        uint32_t *tiles = (uint32_t *)(ws + L.tiles);
+        unsigned short *lists = (unsigned short *)(ws + L.tile_list);
+        float *draws = (float *)(ws + L.tile_draw);
+        if (write_mask) hipLaunchKernelGGL(k_tile_scan_seg2<true>, dim3(total), dim3(kBlock), 0, st, m, tiles, lists, draws);
+        else hipLaunchKernelGGL(k_tile_scan_seg2<false>, dim3(total), dim3(kBlock), 0, st, m, tiles, lists, draws);
+        return check_launch("k_tile_scan_seg2");
+    }
     // (the mask's interpretation -- low byte for v3, == 1 for the estimate -- is a template parameter of the scan)
     auto go = [&](auto es) {
         constexpr int ES = decltype(es)::value;
@@ -563,6 +586,52 @@ int run_scan(const pvv_problem *p, const Front &f, char *ws, const Layout &L, hi
     return check_launch("k_tile_scan");
 }
 
+// ---------------------------------------------------------------------------------------------
+// The side stream: one per device, created on first use, for work of a call that nothing in the call waits for -- today
+// the deferred int64 mask of decode_keypoint (k_mask_from_lists).  Fork: an event recorded on the caller's stream behind
+// the scan, the side stream waits for it; join: an event recorded behind the side kernel, the caller's stream waits for
+// it at the end of run_front -- by then the kernel has long finished, it ran beside the compaction and the count pass.
+// hipStreamWaitEvent takes the event's state at the time of the call, so the events are reused (a ring of 8 pairs).
+// Not used while the caller's stream is capturing (no stream or event is created under capture) or when the stream
+// belongs to a device that is not current.
+// ---------------------------------------------------------------------------------------------
+struct SideStream {
+    hipStream_t st = nullptr;
+    hipEvent_t fork[8] = {}, join[8] = {};
+    int next = 0;
+    bool tried = false, ok = false;
+};
+SideStream g_side[64];
+std::mutex g_side_mu;
+
+bool side_fork(hipStream_t st, hipStream_t *side, hipEvent_t *join)
+{
+    int cur = -1;
+    const int dev = stream_device(st);
+    if (dev < 0 || hipGetDevice(&cur) != hipSuccess || cur != dev) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (cs != hipStreamCaptureStatusNone) return false;
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    SideStream *g = &g_side[dev];
+    if (!g->tried) {
+        g->tried = true;
+        bool ok = hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < 8; ++i)
+            ok = hipEventCreateWithFlags(&g->fork[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&g->join[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        g->ok = ok;
+    }
+    if (!g->ok) return false;
+    const int i = g->next;
+    g->next = (i + 1) & 7;
+    if (hipEventRecord(g->fork[i], st) != hipSuccess || hipStreamWaitEvent(g->st, g->fork[i], 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    *side = g->st;
+    *join = g->join[i];
+    return true;
+}
+
 // mask scan + (subsample) + compaction and hypotheses + counting, shared by both layers.
 int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d_vertex,
               const int32_t *d_idxs, const float *d_selection, char *ws, const Layout &L,
@@ -573,7 +642,19 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
     const Front f = make_front(p, mode, d_mask, d_vertex, d_idxs, d_selection, ws, L, d_tn, d_seg, d_mask_out, d_idxs2,
                                hn_first, stream_first, stream_rest);
     if (int e = mark(p, PVV_MARK_BEGIN, st)) return e;
-    if (int e = run_scan(p, f, ws, L, st)) return e;
+    // the side stream is claimed BEFORE the scan is launched: if it is not to be had the scan writes the mask itself
+    hipStream_t side = nullptr;
+    hipEvent_t join = nullptr;
+    bool deferred = false;
+    if (int e = run_scan(p, f, ws, L, st, !f.mask_deferred)) return e;
+    if (f.mask_deferred) {
+        deferred = side_fork(st, &side, &join);
+        const hipStream_t ms = deferred ? side : st;                // no side stream: the same kernel, in line
+        hipLaunchKernelGGL(k_mask_from_lists, dim3((unsigned)((long long)L.T * p->B)), dim3(kBlock), 0, ms, (const uint32_t *)(ws + L.tiles),
+                           (const unsigned short *)(ws + L.tile_list), f.mask_deferred, L.T, p->H * p->W);
+        if (int e = check_launch("k_mask_from_lists")) return e;
+        if (deferred && hipEventRecord(join, side) != hipSuccess) return fail(PVV_E_ARG, "side stream: hipEventRecord failed");
+    }
     if (!f.m.fuse_sub && f.can_subsample) {
         hipLaunchKernelGGL(k_tile_subsample, dim3(L.T, p->B), dim3(kBlock), 0, st, f.m, (uint32_t *)(ws + L.tiles),
                            (unsigned short *)(ws + L.tile_list), (const float *)(ws + L.tile_draw));
@@ -587,6 +668,7 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
     if (int e = check_launch("k_compact_hyp")) return e;
     if (int e = mark(p, PVV_MARK_COMPACT, st)) return e;
     if (int e = launch_count_any(p, L, ws, st, v3)) return e;
+    if (deferred && hipStreamWaitEvent(st, join, 0) != hipSuccess) return fail(PVV_E_ARG, "side stream: hipStreamWaitEvent failed");
     return mark(p, PVV_MARK_COUNT, st);
 }
 

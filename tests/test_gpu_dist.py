@@ -31,7 +31,7 @@ def test_bench_under_torchrun_one_rank_executes_the_rccl_exchange(gpu):
     assert line["extra"]["rccl_ranks"] == 1 and "all_gather_into_tensor" in line["extra"]["exchange"]
     assert line["config"]["global_batch"] == 4 and line["config"]["batch_per_gpu"] == 4
     assert line["value"] > 0 and line["extra"]["known_answer_max_err_px"] < 20
-    assert len(line["extra"]["per_rank_count_kernel_ms"]) == 1 and line["roofline"]["kernel_ms_avg"] > 0
+    assert len(line["extra"]["per_rank_count_kernel_ms"]) == 1 and line["roofline_contract_count_pass"]["kernel_ms_avg"] > 0 and 0 < line["roofline"]["frac"]
 
 
 _SHARDED = r"""
