@@ -308,33 +308,42 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan_seg2(MaskArgs a, uint32_t 
 }
 
 // The int64 mask of decode_keypoint from the tile lists (two-class seg: mask = 1 exactly on the listed pixels), when
-// k_tile_scan_seg2 did not write it: launched on the library's side stream right behind the scan, it streams its 8 B per
-// pixel beside the compaction and the VALU-bound count pass instead of in front of them.  One tile per block; a store
-// instruction covers 4 KB contiguous.
+// k_tile_scan_seg2 did not write it: launched on the library's side stream behind the compaction, it streams its 8 B per
+// pixel beside the VALU-bound count pass instead of in front of it.  Persistent (the host launches two blocks per
+// CU: the count kernel's blocks leave room for exactly that, and a queue of 10 000 short-lived blocks would compete with
+// the other kernels' dispatch), a tile per trip; a store instruction covers 4 KB contiguous.
 __global__ __launch_bounds__(kBlock) void k_mask_from_lists(const uint32_t *__restrict__ tiles, const unsigned short *__restrict__ tile_list,
-                                                            long long *__restrict__ mask_out, int T, int HW)
+                                                            long long *__restrict__ mask_out, int T, int HW, int total_tiles)
 {
     __shared__ unsigned bm[kTile / 32];
-    const int g = blockIdx.x;
-    const int b = g / T, t = g - b * T;
-    const int nz = (int)(tiles[g] & kTileNzMask);
-    if (nz) {                                                      // (block-uniform)
-        if (threadIdx.x < kTile / 32) bm[threadIdx.x] = 0u;
-        __syncthreads();
-        const unsigned short *list = tile_list + (size_t)g * kTile;
-        for (int e = threadIdx.x; e < nz; e += kBlock) {
-            const unsigned off = list[e];
-            atomicOr(&bm[off >> 5], 1u << (off & 31u));
+    uint32_t word = (int)blockIdx.x < total_tiles ? tiles[blockIdx.x] : 0u;
+    for (int g = blockIdx.x; g < total_tiles; g += gridDim.x) {
+        const int b = g / T, t = g - b * T;
+        const int nz = (int)(word & kTileNzMask);
+        if (g + (int)gridDim.x < total_tiles) word = tiles[g + gridDim.x];   // the next trip's word, requested a trip ahead
+        if (nz) {                                                  // (block-uniform)
+            __syncthreads();                                       // the previous tile's bitmap is consumed
+            if (threadIdx.x < kTile / 32) bm[threadIdx.x] = 0u;
+            __syncthreads();
+            const unsigned short *list = tile_list + (size_t)g * kTile;
+            for (int e = threadIdx.x; e < nz; e += kBlock) {
+                const unsigned off = list[e];
+                atomicOr(&bm[off >> 5], 1u << (off & 31u));
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    long long *dst = mask_out + (int64_t)b * HW + (int64_t)t * kTile;
+        long long *dst = mask_out + (int64_t)b * HW + (int64_t)t * kTile;
 #pragma unroll
-    for (int j = 0; j < kTile / (2 * kBlock); ++j) {
-        const int px = (j * kBlock + (int)threadIdx.x) * 2;        // HW % 4 == 0: a pair is inside or outside
-        if (t * kTile + px >= HW) break;
-        const unsigned w = nz ? bm[px >> 5] >> (px & 31) : 0u;
-        __builtin_nontemporal_store(i64x2{(long long)(w & 1u), (long long)((w >> 1) & 1u)}, (i64x2 *)(dst + px));
+        for (int j = 0; j < kTile / (2 * kBlock); ++j) {
+            const int px = (j * kBlock + (int)threadIdx.x) * 2;    // HW % 4 == 0: a pair is inside or outside
+            if (t * kTile + px >= HW) break;
+            const unsigned w = nz ? bm[px >> 5] >> (px & 31) : 0u;
+#ifdef PVV_MASK_PLAIN_STORE                                            // (tuning builds: A/B of the store policy)
+            *(i64x2 *)(dst + px) = i64x2{(long long)(w & 1u), (long long)((w >> 1) & 1u)};
+#else
+            __builtin_nontemporal_store(i64x2{(long long)(w & 1u), (long long)((w >> 1) & 1u)}, (i64x2 *)(dst + px));
+#endif
+        }
     }
 }
 

@@ -604,14 +604,15 @@ struct SideStream {
 SideStream g_side[64];
 std::mutex g_side_mu;
 
-bool side_fork(hipStream_t st, hipStream_t *side, hipEvent_t *join)
+// can work of a call on `st` be forked to the side stream?  (creates it on first use)
+SideStream *side_get(hipStream_t st)
 {
     int cur = -1;
     const int dev = stream_device(st);
-    if (dev < 0 || hipGetDevice(&cur) != hipSuccess || cur != dev) return false;
+    if (dev < 0 || hipGetDevice(&cur) != hipSuccess || cur != dev) return nullptr;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (cs != hipStreamCaptureStatusNone) return false;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
     std::lock_guard<std::mutex> lock(g_side_mu);
     SideStream *g = &g_side[dev];
     if (!g->tried) {
@@ -623,7 +624,14 @@ bool side_fork(hipStream_t st, hipStream_t *side, hipEvent_t *join)
         if (!ok) (void)hipGetLastError();
         g->ok = ok;
     }
-    if (!g->ok) return false;
+    return g->ok ? g : nullptr;
+}
+
+bool side_fork(hipStream_t st, hipStream_t *side, hipEvent_t *join)
+{
+    SideStream *g = side_get(st);
+    if (!g) return false;
+    std::lock_guard<std::mutex> lock(g_side_mu);
     const int i = g->next;
     g->next = (i + 1) & 7;
     if (hipEventRecord(g->fork[i], st) != hipSuccess || hipStreamWaitEvent(g->st, g->fork[i], 0) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -642,19 +650,12 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
     const Front f = make_front(p, mode, d_mask, d_vertex, d_idxs, d_selection, ws, L, d_tn, d_seg, d_mask_out, d_idxs2,
                                hn_first, stream_first, stream_rest);
     if (int e = mark(p, PVV_MARK_BEGIN, st)) return e;
-    // the side stream is claimed BEFORE the scan is launched: if it is not to be had the scan writes the mask itself
     hipStream_t side = nullptr;
     hipEvent_t join = nullptr;
     bool deferred = false;
-    if (int e = run_scan(p, f, ws, L, st, !f.mask_deferred)) return e;
-    if (f.mask_deferred) {
-        deferred = side_fork(st, &side, &join);
-        const hipStream_t ms = deferred ? side : st;                // no side stream: the same kernel, in line
-        hipLaunchKernelGGL(k_mask_from_lists, dim3((unsigned)((long long)L.T * p->B)), dim3(kBlock), 0, ms, (const uint32_t *)(ws + L.tiles),
-                           (const unsigned short *)(ws + L.tile_list), f.mask_deferred, L.T, p->H * p->W);
-        if (int e = check_launch("k_mask_from_lists")) return e;
-        if (deferred && hipEventRecord(join, side) != hipSuccess) return fail(PVV_E_ARG, "side stream: hipEventRecord failed");
-    }
+    // no side stream to be had (the caller's stream is being captured, ...): the scan writes the mask itself
+    const bool defer_mask = f.mask_deferred && tuning_int("PVV_MASK_DEFER", 1) != 0 && side_get(st) != nullptr;
+    if (int e = run_scan(p, f, ws, L, st, !defer_mask)) return e;
     if (!f.m.fuse_sub && f.can_subsample) {
         hipLaunchKernelGGL(k_tile_subsample, dim3(L.T, p->B), dim3(kBlock), 0, st, f.m, (uint32_t *)(ws + L.tiles),
                            (unsigned short *)(ws + L.tile_list), (const float *)(ws + L.tile_draw));
@@ -667,6 +668,18 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
                        (float2 *)(ws + L.dirs));
     if (int e = check_launch("k_compact_hyp")) return e;
     if (int e = mark(p, PVV_MARK_COMPACT, st)) return e;
+    if (defer_mask) {
+        // forked BEHIND the compaction (measured: forked behind the scan, the 157 MB of stores cost the latency-bound
+        // compaction +14 us at B = 64 and the count pass +9; the count pass alone is 130 us of mostly VALU work)
+        deferred = side_fork(st, &side, &join);
+        const hipStream_t ms = deferred ? side : st;                // no side stream: the same kernel, in line
+        const long long total = (long long)L.T * p->B;
+        const int grid = (int)std::min<long long>(total, (long long)tuning_int("PVV_MASK_GRID_PER_CU", 2) * num_cus());
+        hipLaunchKernelGGL(k_mask_from_lists, dim3(grid), dim3(kBlock), 0, ms, (const uint32_t *)(ws + L.tiles),
+                           (const unsigned short *)(ws + L.tile_list), f.mask_deferred, L.T, p->H * p->W, (int)total);
+        if (int e = check_launch("k_mask_from_lists")) return e;
+        if (deferred && hipEventRecord(join, side) != hipSuccess) return fail(PVV_E_ARG, "side stream: hipEventRecord failed");
+    }
     if (int e = launch_count_any(p, L, ws, st, v3)) return e;
     if (deferred && hipStreamWaitEvent(st, join, 0) != hipSuccess) return fail(PVV_E_ARG, "side stream: hipStreamWaitEvent failed");
     return mark(p, PVV_MARK_COUNT, st);
@@ -738,7 +751,9 @@ static int finish_v3(const pvv_problem *p, const Layout &L, char *ws, float *d_o
     if (band) launch_refit(k_select_refit<true>); else launch_refit(k_select_refit<false>);
     if (int e = check_launch("k_select_refit")) return e;
     if (int e = mark(p, PVV_MARK_SELECT, st)) return e;
-    float *hint = stage_hint_claim(p, st);
+    // the stage hint is only ever consulted by AUTO for problems that may stage: other calls do not write it (a store to
+    // host-visible memory at the end of a 3 us kernel: the reference's own eval batch is B = 1)
+    float *hint = (p->count_kernel == PVV_COUNT_AUTO && may_stage(p)) ? stage_hint_claim(p, st) : nullptr;
     hipLaunchKernelGGL(k_finalize_v3, dim3(p->B), dim3(64), 0, st, (const int *)(ws + L.tn),
                        (const double *)(ws + L.sums), (float2 *)d_out, p->K, p->singular_policy, nsplit,
                        (const float *)(ws + L.ratio), hint, kMaxBatchLds);

@@ -97,7 +97,7 @@ def test_reference_glue_on_hip_kernels_equals_golden_and_the_fused_layer(oracle,
         tol.assert_means_close(ours, other, extra=np.abs(other - exact), what="ours vs " + what)
     tol.assert_means_close(out_ref, c["out"], extra=np.abs(c["out"] - exact) + np.abs(out_ref - exact),
                            what="reference glue on the HIP kernels vs golden")
-    assert dev(out_ref, c["out"]) < 1e-3
+    assert bool((np.abs(out_ref.astype(np.float64) - c["out"]) <= 1e-3 + 1e-6 * np.abs(c["out"])).all())   # (v3_singular returns ATb: ~3e4)
 
 
 @pytest.mark.parametrize("name", ["estimate_basic", "estimate_subsample"])

@@ -35,6 +35,7 @@ def _load(path):
     vp = ctypes.c_void_p
     L.pvv_ransac_voting_v3.argtypes = [ctypes.POINTER(capi.Problem), vp, vp, vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp]
     L.pvv_rerun_count_kernel.argtypes = [ctypes.POINTER(capi.Problem), vp, ctypes.c_size_t, ctypes.c_int, vp]
+    L.pvv_decode_keypoint_v3.argtypes = [ctypes.POINTER(capi.Problem), vp, vp, vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp, vp]
     return L
 
 
@@ -46,8 +47,9 @@ def main():
     ap.add_argument("--hn", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=30)
     ap.add_argument("--per-group", type=int, default=10)
-    ap.add_argument("--mode", default="count", choices=["count", "v3"],
-                    help="count: re-launches of the inlier-count kernel; v3: whole pvv_ransac_voting_v3 calls")
+    ap.add_argument("--mode", default="count", choices=["count", "v3", "decode"],
+                    help="count: re-launches of the inlier-count kernel; v3: whole pvv_ransac_voting_v3 calls; decode: whole "
+                         "pvv_decode_keypoint_v3 calls on seg logits + the planar vertex view (one [B,2+2K,H,W] tensor, resnet18.py:93)")
     ap.add_argument("--rotate", type=int, default=1, help="v3 mode: cycle over this many distinct device-resident batches (cold caches)")
     a = ap.parse_args()
     synth = _synth()
@@ -61,6 +63,17 @@ def main():
     others = [synth.make_batch(B, cfg["H"], cfg["W"], cfg["K"], device=dev, seed=50 + i,
                                **{k: v for k, v in cfg.items() if k not in ("B", "H", "W", "K", "hn")}) for i in range(a.rotate - 1)]
     st = capi.stream()
+    net = []
+    if a.mode == "decode":           # the network's output tensor per rotating batch: seg = x[:, :2], vertex = the planar view of x[:, 2:]
+        for o in [d] + others:
+            K = cfg["K"]
+            x = torch.empty(B, 2 + 2 * K, cfg["H"], cfg["W"], device=dev)
+            x[:, 0] = 3.0 * (o["mask"] == 0)
+            x[:, 1] = 3.0 * (o["mask"] != 0)
+            x[:, 2:] = o["vertex"].permute(0, 3, 4, 1, 2).reshape(B, 2 * K, cfg["H"], cfg["W"])
+            net.append((x, x[:, :2], x[:, 2:].permute(0, 2, 3, 1).view(B, cfg["H"], cfg["W"], K, 2),
+                        torch.empty(B, cfg["H"], cfg["W"], dtype=torch.int64, device=dev)))
+        vertex = net[0][2]
     runs = []
     for spec in a.libs:
         # "lib.so@PVV_GRID_PER_CU=30,PVV_X=1": environment for THIS build only (the library reads its knobs once, at
@@ -87,6 +100,9 @@ def main():
         p.mask_stride[:] = mask.stride()
         p.vertex_stride[:] = vertex.stride()
         p.seed = 12345
+        if a.mode == "decode":
+            p.seg_classes = 2
+            p.seg_stride[:] = net[0][1].stride()
         n = L.pvv_workspace_bytes(ctypes.byref(p))
         ws = torch.empty(n, dtype=torch.uint8, device=dev)
         out = torch.empty(p.B, p.K, 2, device=dev)
@@ -108,10 +124,17 @@ def main():
                 os.environ[k] = v
         rot = [args] + [(ctypes.byref(p), capi.ptr(o["mask"]), capi.ptr(o["vertex"]), None, None, capi.ptr(ws), n, capi.ptr(out),
                          capi.ptr(win), capi.ptr(tn), st) for o in others]
+        if a.mode == "decode":
+            rot = [(ctypes.byref(p), capi.ptr(sg), capi.ptr(vx), None, None, capi.ptr(ws), n, capi.ptr(mo), capi.ptr(out), capi.ptr(win),
+                    capi.ptr(tn), st) for (_x, sg, vx, mo) in net]
         runs.append(dict(path=spec, L=L, p=p, ws=ws, n=n, win=int(win.sum().item()), out=out.double().sum().item(), ms=[],
                          args=args, rot=rot, k=0, keep=(out, win, tn)))
     def launch(r):
-        if a.mode == "v3":
+        if a.mode == "decode":
+            r["k"] += 1
+            rc = r["L"].pvv_decode_keypoint_v3(*r["rot"][r["k"] % len(r["rot"])])
+            assert rc == 0, r["L"].pvv_last_error()
+        elif a.mode == "v3":
             r["k"] += 1
             r["L"].pvv_ransac_voting_v3(*r["rot"][r["k"] % len(r["rot"])])
         else:
@@ -130,6 +153,10 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             r["ms"].append(e0.elapsed_time(e1) / a.per_group)
+    if a.mode == "decode":
+        for r in runs:
+            r["mask_sum"] = int(net[r["k"] % len(net)][3].sum().item())
+            r["win"], r["out"] = int(r["keep"][1].sum().item()), r["keep"][0].double().sum().item()
     base = None
     for r in runs:
         t = torch.tensor(r["ms"], dtype=torch.float64)
@@ -137,7 +164,7 @@ def main():
         base = base or mean
         print(json.dumps({"lib": os.path.basename(r["path"]), "mode": a.mode, "config": a.config, "B": B, "hn": hn,
                           "ms_mean": round(mean, 4), "ms_sem": round(sem, 5), "ms_min": round(t.min().item(), 4),
-                          "ratio": round(mean / base, 4), "win_sum": r["win"], "out_sum": round(r["out"], 3)}), flush=True)
+                          "ratio": round(mean / base, 4), "win_sum": r["win"], "out_sum": round(r["out"], 3), "mask_sum": r.get("mask_sum")}), flush=True)
 
 
 if __name__ == "__main__":
