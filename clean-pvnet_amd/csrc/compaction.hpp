@@ -463,6 +463,7 @@ struct HypArgs {
     int blocks;              // hypothesis blocks per image
     int *surv;               // [B, kSurvCap] scratch: the survivors of a heavily subsampled image (see k_compact_hyp)
     int *lead;               // [B,K,8] or null: leader counts of the staged count pass (count_prune.hpp); [4..7] zeroed here
+    int *miss;               // [B,K,hn] or null: the staged pass's shared miss counters (count_filter_runs.hpp), zeroed here
 };
 
 constexpr int kHypRejectTries = 1 << 12;
@@ -583,6 +584,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
         const int vi = gid / h.hn, hi = gid - vi * h.hn;
         const size_t o = ((size_t)b * v.K + vi) * h.hn + hi;
         h.counts[o] = 0;
+        if (h.miss) h.miss[o] = 0;
         if (h.lead && hi == 0) {                                  // all four, whatever hn is (hi < min(4, hn) left words unzeroed for hn < 4)
             int *lw = h.lead + ((size_t)b * v.K + vi) * 8 + 4;
             lw[0] = 0; lw[1] = 0; lw[2] = 0; lw[3] = 0;

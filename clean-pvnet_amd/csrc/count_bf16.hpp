@@ -133,6 +133,8 @@ struct StageArgs {
                           // pixels the first launch did not count [4..7] (k_lead)
     int *any_staged;      // one word: kCountFirst writes whether ANY image is staged; k_lead and kCountFilter leave at once
                           // when none is (a batch of small masks then pays two empty launches, not two table builds)
+    int *miss;            // k_count_filter_runs: [B,K,hn] misses proven so far among the pixels the first launch did not count
+                          // (zeroed by k_compact_hyp; count_filter_runs.hpp)
 };
 
 // chunks with a residue in `mask` among the first n chunks, and the j-th of them (residues present in a last, partial

@@ -62,6 +62,7 @@ int check_launch(const char *what)
 #include "compaction.hpp"
 #include "count_exact.hpp"
 #include "count_bf16.hpp"
+#include "count_filter_runs.hpp"
 #include "count_prune.hpp"
 #include "refit.hpp"
 #include "covariance.hpp"
@@ -77,6 +78,7 @@ struct Layout {
     size_t tiles, tile_list, tile_draw, tn, surv, coords, dirs, hyps, counts, sums, total;
     size_t lead;                                     // staged counting (count_prune.hpp): [B,K,8] leader counts; 0 = not reserved
     size_t ratio;                                    // [B,K] winner count / tn (k_select_refit -> k_finalize_v3 -> stage hint)
+    size_t miss;                                     // staged counting: [B,K,hn] shared miss counters (count_filter_runs.hpp); 0 = not reserved
 };
 
 bool use_bf16_count(const pvv_problem *p);
@@ -101,6 +103,7 @@ Layout make_layout(const pvv_problem *p)
     L.sums = take(sizeof(double) * (size_t)p->B * p->K * kRefitSplitMax * 5);
     L.ratio = take(sizeof(float) * (size_t)p->B * p->K);
     L.lead = may_stage(p) ? take(sizeof(int) * ((size_t)p->B * p->K * 8 + 1)) : 0;   // + the any_staged word
+    L.miss = may_stage(p) ? take(sizeof(int) * (size_t)p->B * p->K * p->hn) : 0;
     L.total = off;
     return L;
 }
@@ -282,6 +285,27 @@ float stage_hint_mean(const pvv_problem *p, hipStream_t st, float *max_tn = null
     return cnt ? (float)(sum / cnt) : -1.f;
 }
 
+// Chunks the SECOND launch of a staged pass would walk, summed over the images the last call of this shape reported (-1: no
+// data): the host's preview of the run length k_count_filter_runs will pick (count_filter_runs.hpp).
+long long stage_hint_rest_chunks(const pvv_problem *p, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    StageHint *g = stage_hint_locked(st, false);
+    if (!g || g->n <= 0) return -1;
+    const int shape[5] = {p->B, p->H, p->W, p->K, p->hn};
+    if (memcmp(g->shape, shape, sizeof(shape)) != 0) return -1;
+    const volatile float *r = g->ratio;
+    long long total = 0;
+    constexpr int PC = 4 * kBfPixPerWave;
+    for (int i = 0; i < g->n; ++i) {
+        if (r[i] < -1.5f) return -1;                                      // an image of the last call has not reported yet
+        const int nch = ((int)r[kMaxBatchLds + i] + PC - 1) / PC;
+        if (nch >= kStageMinChunks)
+            total += (nch / kStageM) * __builtin_popcount(kStageRest) + __builtin_popcount(kStageRest & ((1u << (nch % kStageM)) - 1u));
+    }
+    return total;
+}
+
 // the break-even ratio from the measurements above: lower for more work per call and for more hypotheses per keypoint
 float stage_hint_threshold(const pvv_problem *p)
 {
@@ -408,6 +432,7 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     StageArgs sa;
     sa.lead = nullptr;
     sa.any_staged = lead + (size_t)p->B * p->K * 8;
+    sa.miss = (int *)(ws + L.miss);
     hipLaunchKernelGGL(k_count_bf16<kCountFirst>, dim3(per_cu_first * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
                        p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target_first, dbg, sa);
     if (int e = check_launch("k_count_bf16<first>")) return e;
@@ -426,6 +451,18 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     if (int e = check_launch("k_lead")) return e;
     if (int e = mark(p, PVV_MARK_PRUNE0, st)) return e;
     sa.lead = lead;
+    // round 4: the second launch's items own a RUN of an (image, keypoint)'s remaining chunks and keep eliminating inside it
+    // (count_filter_runs.hpp); one generation of blocks, the run length adapts the item count to it.  (Round 3's
+    // one-chunk items stay reachable in tuning builds: PVV_FILTER_OLD=1.)
+    // With runs of ONE chunk the new items only add their elimination step to round 3's (+2 % per call at config 3, B = 16 / 24):
+    // when the images the last call of this shape reported (the stage hint: AUTO only) predict that, round 3's kernel runs.
+    const long long rest = p->count_kernel == PVV_COUNT_AUTO ? stage_hint_rest_chunks(p, st) : -1;
+    const bool runs = rest < 0 || rest * p->K >= 2ll * target_filter;
+    if (tuning_int("PVV_FILTER_OLD", runs ? 0 : 1) == 0) {
+        hipLaunchKernelGGL(k_count_filter_runs, dim3(tuning_int("PVV_GRID_PER_CU_FILTER", 5) * num_cus()), dim3(kBlock), 0, st, coords, dirs,
+                           hyps, counts, tn, p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target_filter, tuning_int("PVV_RUN_R", 0), sa);
+        return check_launch("k_count_filter_runs");
+    }
     hipLaunchKernelGGL(k_count_bf16<kCountFilter>, dim3(per_cu_filter * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
                        p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target_filter, dbg, sa);
     return check_launch("k_count_bf16<filter>");
@@ -556,6 +593,7 @@ Front make_front(const pvv_problem *p, int mode, const void *d_mask, const float
     h.blocks = (int)(((long long)p->K * p->hn + kBlock - 1) / kBlock);
     h.surv = (int *)(ws + L.surv);
     h.lead = L.lead ? (int *)(ws + L.lead) : nullptr;
+    h.miss = L.miss ? (int *)(ws + L.miss) : nullptr;
     return f;
 }
 
@@ -647,8 +685,9 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
               const int32_t *d_idxs2 = nullptr, int hn_first = -1, uint32_t stream_first = 1u, uint32_t stream_rest = 3u,
               bool v3 = false)
 {
-    const Front f = make_front(p, mode, d_mask, d_vertex, d_idxs, d_selection, ws, L, d_tn, d_seg, d_mask_out, d_idxs2,
-                               hn_first, stream_first, stream_rest);
+    Front f = make_front(p, mode, d_mask, d_vertex, d_idxs, d_selection, ws, L, d_tn, d_seg, d_mask_out, d_idxs2,
+                         hn_first, stream_first, stream_rest);
+    if (!v3) f.h.miss = nullptr;                                    // only a v3 call can count in stages: nothing else reads (or zeroes) them
     if (int e = mark(p, PVV_MARK_BEGIN, st)) return e;
     hipStream_t side = nullptr;
     hipEvent_t join = nullptr;
@@ -879,6 +918,7 @@ PVV_EXPORT int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace, s
     if (zero_counts) {
         hipError_t e = hipMemsetAsync(ws + L.counts, 0, sizeof(int) * (size_t)p->B * p->K * p->hn, st);
         if (e == hipSuccess && L.lead) e = hipMemsetAsync(ws + L.lead, 0, sizeof(int) * ((size_t)p->B * p->K * 8 + 1), st);
+        if (e == hipSuccess && L.miss) e = hipMemsetAsync(ws + L.miss, 0, sizeof(int) * (size_t)p->B * p->K * p->hn, st);
         if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     }
     return launch_count_any(p, L, ws, st, v3);
