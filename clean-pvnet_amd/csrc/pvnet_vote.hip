@@ -306,12 +306,26 @@ long long stage_hint_rest_chunks(const pvv_problem *p, hipStream_t st)
     return total;
 }
 
-// the break-even ratio from the measurements above: lower for more work per call and for more hypotheses per keypoint
+// The break-even winner ratio, from one-process A/B measurements of whole calls on MI355X with the round-4 second launch
+// (k_count_filter_runs; tools/staged_ab.py --outlier ..., profiles/r04_staged_ab_outliers.json): 480x640, K = 9,
+// 512 hypotheses breaks even at rho = 0.990 for B = 16, 0.966 for 24, 0.957 for 32, 0.91 for 48, 0.765 for 64 and below 0.6
+// for 128 (round 3's kernel: 0.976 / 0.941 / 0.906 at B = 16 / 32 / 64); 540x720, K = 17, 2048 hypotheses at B = 16 gains at
+// every ratio measured (+10 % at 0.71).  Interpolated in x = log2(B*K*hn*H*W / 2.26e10); more hypotheses per keypoint
+// lower it further.
 float stage_hint_threshold(const pvv_problem *p)
 {
-    const double work = (double)p->B * p->K * p->hn * p->H * p->W;
-    double thr = 0.976 - 0.035 * std::log2(work / 2.26e10) - 0.1 * std::log2(std::max(p->hn, 512) / 512.0);
-    return (float)std::min(0.985, std::max(0.5, thr));
+    static const double xs[6] = {0.0, 0.585, 1.0, 1.585, 2.0, 3.0}, ys[6] = {0.990, 0.966, 0.957, 0.910, 0.765, 0.50};
+    const double x = std::log2((double)p->B * p->K * p->hn * p->H * p->W / 2.26e10);
+    double thr;
+    if (x <= xs[0]) thr = ys[0] + (ys[1] - ys[0]) / (xs[1] - xs[0]) * (x - xs[0]);
+    else if (x >= xs[5]) thr = ys[5];
+    else {
+        int i = 0;
+        while (x > xs[i + 1]) ++i;
+        thr = ys[i] + (ys[i + 1] - ys[i]) * (x - xs[i]) / (xs[i + 1] - xs[i]);
+    }
+    thr -= 0.1 * std::log2(std::max(p->hn, 512) / 512.0);
+    return (float)std::min(0.995, std::max(0.5, thr));
 }
 
 bool stage_hint_allows(const pvv_problem *p, hipStream_t st)

@@ -313,7 +313,7 @@ def test_auto_follows_the_stage_hint(synth, pkg, gpu):
         valid, mean, thr = ext.stage_hint(d["mask"], d["vertex"], hn)
         ratio = float((win.double() / tn.double().view(-1, 1)).mean())
         assert valid and abs(mean - ratio) < 1e-4, (mean, ratio)
-        assert 0.5 <= thr <= 0.985 and (mean >= thr) == want_staged, (mean, thr)
+        assert 0.5 <= thr <= 0.995 and (mean >= thr) == want_staged, (mean, thr)
         ms = ext.stage_ms_in_pipeline([d["mask"]], [d["vertex"]], hn, 0.99, 5, 30000, 5, 3, ext.COUNT_AUTO)
         assert all((r[5] > 0) == want_staged for r in ms), ms     # the first count launch's mark: recorded iff staged
         ref = v3(d, ext.COUNT_FULL)
@@ -322,3 +322,28 @@ def test_auto_follows_the_stage_hint(synth, pkg, gpu):
         # the explicit modes ignore the hint
         assert all(r[5] > 0 for r in ext.stage_ms_in_pipeline([d["mask"]], [d["vertex"]], hn, 0.99, 5, 30000, 5, 2, ext.COUNT_STAGED))
         assert all(r[5] < 0 for r in ext.stage_ms_in_pipeline([d["mask"]], [d["vertex"]], hn, 0.99, 5, 30000, 5, 2, ext.COUNT_FULL))
+
+
+@pytest.mark.parametrize("B,H,W,K,hn,fg,outlier,what", [
+    (40, 240, 320, 2, 1536, 0.30, 0.40, "three 512-hypothesis groups, most of them survive: several passes, runs of 2"),
+    (96, 200, 320, 4, 512, (0.10, 0.45), 0.05, "ragged images (13 ... 57 chunks): long runs of unequal length"),
+    (6, 480, 640, 3, 2048, 0.098, 0.0, "30 000 pixels per image, few items: runs of one chunk, four groups in one pass"),
+    (12, 300, 400, 17, 700, 0.25, 0.15, "hn not a multiple of 32 or 512, 17 keypoints"),
+])
+def test_run_owning_filter_launch_branches(synth, pkg, gpu, B, H, W, K, hn, fg, outlier, what):
+    """k_count_filter_runs (round 4: the staged pass's second launch -- runs of chunks, passes over hypothesis groups,
+    cooperative progressive elimination through the shared miss counters): winners, winner counts, tn and keypoints of
+    PVV_COUNT_STAGED equal those of the full pass bit for bit, on shapes that take its less-travelled branches; repeated
+    calls give identical results (the elimination's timing may differ from call to call, its outcome may not)."""
+    from clean_pvnet_amd import ransac_voting as ext
+    d = synth.make_batch(B=B, H=H, W=W, K=K, fg=fg, sigma=0.05, outlier=outlier, seed=4000 + B, device=gpu)
+    m, v = d["mask"], d["vertex"]
+    full = ext.ransac_voting_v3(m, v, hn, 0.99, 5, 30000, None, None, 31, ext.SINGULAR_ZERO, count_kernel=ext.COUNT_FULL)
+    tn = full[2].cpu()
+    assert int((tn >= 8 * 512 - 511).sum()) >= B // 2, "the case should stage most images: %s" % tn.tolist()
+    for rep in range(3):
+        st = ext.ransac_voting_v3(m, v, hn, 0.99, 5, 30000, None, None, 31, ext.SINGULAR_ZERO, count_kernel=ext.COUNT_STAGED)
+        for a_, b_, nm in zip(st[:3], full[:3], ("keypoints", "winner counts", "tn")):
+            assert torch.equal(a_, b_), (what, nm, rep)
+    ms = ext.stage_ms_in_pipeline([m], [v], hn, 0.99, 5, 30000, 31, 2, ext.COUNT_STAGED)
+    assert all(r[5] > 0 for r in ms)                              # it WAS staged (the first launch's mark was recorded)
