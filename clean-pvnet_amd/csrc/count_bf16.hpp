@@ -125,7 +125,13 @@ enum { kCountFull = 0, kCountFirst = 1, kCountFilter = 2 };
 #define PVV_STAGE_FIRST 0x22u
 #endif
 constexpr int kStageM = PVV_STAGE_M;
-constexpr uint32_t kStageFirst = PVV_STAGE_FIRST, kStageRest = ((1u << kStageM) - 1u) & ~kStageFirst;
+constexpr uint32_t kStageFirst = PVV_STAGE_FIRST;
+// Round 4: with the second launch eliminating as it goes (count_filter_runs.hpp) a SMALLER first stage pays once its runs are
+// long: an eighth of the chunks ({1} of 8) instead of a quarter is -4 % per call at config 3 / B = 128 and -9 % on config 5 /
+// B = 16, +3 % at B = 64 and below (one-process A/B).  The schedule is a template parameter of the three kernels
+// of the pass; the host picks it from the problem's size (launch_count_bf16).
+constexpr uint32_t kStageFirstEighth = 0x02u;
+constexpr uint32_t stage_rest_of(uint32_t first) { return ((1u << kStageM) - 1u) & ~first; }
 constexpr int kStageMinChunks = 8;
 
 struct StageArgs {
@@ -161,7 +167,7 @@ __device__ __forceinline__ int stage_pixels(int tn, int nch, int PC)
 }
 
 // 5 blocks (= 5 waves per SIMD) per CU: <= 96 VGPRs and 30 KB of LDS per block; measured -4.4 % against 4
-template <int MODE>
+template <int MODE, uint32_t FIRST = kStageFirst>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_count_bf16(
     const float2 *__restrict__ coords /*[B,cap]*/, const float2 *__restrict__ dirs /*[B,K,cap]*/,
     const float2 *__restrict__ hyps /*[B,K,hn]*/, int *__restrict__ counts /*[B,K,hn]*/,
@@ -181,6 +187,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     __shared__ int s_keep[8];                                   // kCountFilter: kept hypotheses per (pass, wave) of a group
     constexpr bool STAGED = MODE != kCountFull;
     constexpr bool FILTER = MODE == kCountFilter;
+    constexpr uint32_t REST = stage_rest_of(FIRST);
     const int lane = lane_id(), wave = wave_id();
     constexpr int PC = 4 * kBfPixPerWave;
     const int nt = (hn + 31) >> 5;                  // 32-hypothesis tiles per keypoint
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 const unsigned long long sm = __ballot(small);
                 any_staged |= sm != ~0ull;
                 if (lane == 0) s_small[b0 >> 6] = sm;
-                inc = small ? (MODE == kCountFirst ? inc : 0) : stage_chunks<MODE == kCountFirst ? kStageFirst : kStageRest>(inc);
+                inc = small ? (MODE == kCountFirst ? inc : 0) : stage_chunks<MODE == kCountFirst ? FIRST : REST>(inc);
             }
             inc = wave_incl_scan(inc) + carry;
             if (b < B) chunk_end[b] = inc;
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         const int b = locate_item(chunk_end, B, gchunk, &local);   // image, and the chunk's index within it (this stage's)
         int chunk = local;
         if constexpr (STAGED)
-            if (!((s_small[b >> 6] >> (b & 63)) & 1ull)) chunk = stage_chunk_at<MODE == kCountFirst ? kStageFirst : kStageRest>(local);
+            if (!((s_small[b >> 6] >> (b & 63)) & 1ull)) chunk = stage_chunk_at<MODE == kCountFirst ? FIRST : REST>(local);
         const int vi = nruns == 1 ? rem : rem / nruns;          // (one run per (chunk, keypoint) unless the batch is tiny)
         const int run = rem - vi * nruns;
         const int bk = b * K + vi;
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         // kCountFilter: R = pixels of the image the first launch did not count; L* = the larger of the leaders' lower bounds (k_lead)
         int R_rem = 0, lstar = 0, ns_g = 0;
         if constexpr (FILTER) {
-            R_rem = stage_pixels<kStageRest>(tn, (tn + PC - 1) / PC, PC);
+            R_rem = stage_pixels<REST>(tn, (tn + PC - 1) / PC, PC);
             int full = lead_p >= 0 ? lead_p + lead_r : -1;
             full = max(full, PVV_DPP(full, full, 0xB1, 0xf, false));   // quad_perm [1,0,3,2]
             full = max(full, PVV_DPP(full, full, 0x4E, 0xf, false));   // quad_perm [2,3,0,1]: lanes 0-3 hold the four leaders' maximum

@@ -51,6 +51,7 @@ __device__ __forceinline__ int stage_hypothesis_b(bf16x8 *sB, int i, float2 hp, 
     return !(fabsf(hp.x) < 1e15f && fabsf(hp.y) < 1e15f);
 }
 
+template <uint32_t FIRST>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_count_filter_runs(
     const float2 *__restrict__ coords /*[B,cap]*/, const float2 *__restrict__ dirs /*[B,K,cap]*/,
     const float2 *__restrict__ hyps /*[B,K,hn]*/, int *__restrict__ counts /*[B,K,hn]*/,
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     const int lane = lane_id(), wave = wave_id();
     constexpr int PC = 4 * kBfPixPerWave;
     constexpr int GH = kRunSlots;                   // hypotheses per group
+    constexpr uint32_t REST = stage_rest_of(FIRST);  // the chunks the first launch left
     const int nhg = (hn + GH - 1) / GH;             // hypothesis groups per keypoint
     if (*sa.any_staged == 0) return;
 
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             int n = 0;
             if (b < B) {
                 const int nch = (tn_arr[b] + PC - 1) / PC;
-                n = nch < kStageMinChunks ? 0 : stage_chunks<kStageRest>(nch);
+                n = nch < kStageMinChunks ? 0 : stage_chunks<REST>(nch);
                 run_end[b] = n;
             }
             total += wave_total(n);
@@ -127,10 +129,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         int *miss_k = sa.miss + (size_t)bk * hn;
         const int tn = __builtin_amdgcn_readfirstlane(tn_arr[b]);
         const int nch = (tn + PC - 1) / PC;
-        const int nrest = stage_chunks<kStageRest>(nch);         // remaining chunks of the image (>= 1: the image is staged)
+        const int nrest = stage_chunks<REST>(nch);         // remaining chunks of the image (>= 1: the image is staged)
         const int nruns = (nrest + R - 1) / R;
         const int j0 = (int)((long long)r_img * nrest / nruns), j1 = (int)((long long)(r_img + 1) * nrest / nruns);
-        const int R_rem = stage_pixels<kStageRest>(tn, nch, PC);  // pixels of the image the first launch did not count
+        const int R_rem = stage_pixels<REST>(tn, nch, PC);  // pixels of the image the first launch did not count
         // L* = the larger of the leaders' lower bounds (k_lead)
         int lstar;
         {
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             if (ns == 0) continue;                               // nobody of these groups can still reach L*
 
             for (int j = j0; j < j1 && ns > 0; ++j) {
-                const int chunk = stage_chunk_at<kStageRest>(j);
+                const int chunk = stage_chunk_at<REST>(j);
                 const int pb = chunk * PC;                       // first pixel of the chunk (< tn)
                 int tid = threadIdx.x;
                 asm volatile("" : "+v"(tid));                    // (see k_count_bf16: keeps the prologue's indices out of the loop's registers)

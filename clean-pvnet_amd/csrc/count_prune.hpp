@@ -39,8 +39,10 @@ struct LeadArgs {
 
 constexpr int kLead = 2;     // leaders per (image, keypoint), <= 4
 
+template <uint32_t FIRST>
 __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
 {
+    constexpr uint32_t REST = stage_rest_of(FIRST);
     __shared__ int s_cnt[4], s_idx[4], s_sum[4][4];
     const int vi = blockIdx.x / a.nsplit, split = blockIdx.x - vi * a.nsplit, b = blockIdx.y, bk = b * a.K + vi;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
     //      The first trip's loads (kTrip pixels per thread) are issued BEFORE the leader search: they depend on tn alone,
     //      so the counts, the pixels and then the leaders' hypotheses are three memory round trips, not five.
     constexpr int kTrip = 10;
-    const int rem_px = stage_pixels<kStageRest>(tn, nch, PC);
+    const int rem_px = stage_pixels<REST>(tn, nch, PC);
     const int per = (rem_px + a.nsplit - 1) / a.nsplit;
     const int r1 = min(rem_px, (split + 1) * per);
     const float2 *crd = a.coords + (size_t)b * a.cap;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
             const int r = r0 + u * kBlock;
             cc[u] = dd_[u] = make_float2(0.f, 0.f);                // zero direction: never an inlier
             if (r < r1) {
-                const int p = stage_chunk_at<kStageRest>(r / PC) * PC + (r & (PC - 1));
+                const int p = stage_chunk_at<REST>(r / PC) * PC + (r & (PC - 1));
                 cc[u] = crd[p];
                 dd_[u] = dir[p];
             }

@@ -287,7 +287,7 @@ float stage_hint_mean(const pvv_problem *p, hipStream_t st, float *max_tn = null
 
 // Chunks the SECOND launch of a staged pass would walk, summed over the images the last call of this shape reported (-1: no
 // data): the host's preview of the run length k_count_filter_runs will pick (count_filter_runs.hpp).
-long long stage_hint_rest_chunks(const pvv_problem *p, hipStream_t st)
+long long stage_hint_rest_chunks(const pvv_problem *p, hipStream_t st, uint32_t rest_mask)
 {
     std::lock_guard<std::mutex> lock(g_hint_mu);
     StageHint *g = stage_hint_locked(st, false);
@@ -301,7 +301,7 @@ long long stage_hint_rest_chunks(const pvv_problem *p, hipStream_t st)
         if (r[i] < -1.5f) return -1;                                      // an image of the last call has not reported yet
         const int nch = ((int)r[kMaxBatchLds + i] + PC - 1) / PC;
         if (nch >= kStageMinChunks)
-            total += (nch / kStageM) * __builtin_popcount(kStageRest) + __builtin_popcount(kStageRest & ((1u << (nch % kStageM)) - 1u));
+            total += (nch / kStageM) * __builtin_popcount(rest_mask) + __builtin_popcount(rest_mask & ((1u << (nch % kStageM)) - 1u));
     }
     return total;
 }
@@ -401,6 +401,69 @@ int mark(const pvv_problem *p, int i, hipStream_t st)
     return PVV_OK;
 }
 
+struct StagedLaunch {
+    const pvv_problem *p;
+    char *ws;
+    const Layout *L;
+    hipStream_t st;
+    Bf16Consts fc;
+    long long *dbg;
+    int per_cu_first, per_cu_filter, target_first, target_filter;
+};
+
+// the three launches of a staged count pass for one chunk schedule (FIRST = the residues mod 8 the first launch counts)
+template <uint32_t FIRST>
+int launch_staged(const StagedLaunch &a)
+{
+    const pvv_problem *p = a.p;
+    const Layout &L = *a.L;
+    char *ws = a.ws;
+    hipStream_t st = a.st;
+    const Bf16Consts fc = a.fc;
+    const float2 *coords = (const float2 *)(ws + L.coords), *dirs = (const float2 *)(ws + L.dirs);
+    const float2 *hyps = (const float2 *)(ws + L.hyps);
+    int *counts = (int *)(ws + L.counts);
+    const int *tn = (const int *)(ws + L.tn);
+    int *lead = (int *)(ws + L.lead);
+    StageArgs sa;
+    sa.lead = nullptr;
+    sa.any_staged = lead + (size_t)p->B * p->K * 8;
+    sa.miss = (int *)(ws + L.miss);
+    hipLaunchKernelGGL((k_count_bf16<kCountFirst, FIRST>), dim3(a.per_cu_first * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
+                       p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, a.target_first, a.dbg, sa);
+    if (int e = check_launch("k_count_bf16<first>")) return e;
+    if (int e = mark(p, PVV_MARK_STAGE0, st)) return e;
+    LeadArgs la;
+    la.tn_arr = tn; la.coords = coords; la.dirs = dirs; la.hyps = hyps; la.counts = counts; la.lead = lead;
+    la.K = p->K; la.hn = p->hn; la.cap = p->cap;
+    la.kappa = fc.kappa; la.beta = 2.f * fc.beta2; la.eps = 2.f * fc.eps0;
+    la.any_staged = sa.any_staged;
+    // shares per (image, keypoint): the largest power of two <= 16 that keeps the grid within one generation of blocks
+    // (8 per CU)
+    la.nsplit = 16;
+    while (la.nsplit > 1 && (long long)p->B * p->K * la.nsplit > 8ll * num_cus()) la.nsplit >>= 1;
+    la.nsplit = tuning_int("PVV_LEAD_SPLIT", la.nsplit);
+    hipLaunchKernelGGL(k_lead<FIRST>, dim3(p->K * la.nsplit, p->B), dim3(kBlock), 0, st, la);
+    if (int e = check_launch("k_lead")) return e;
+    if (int e = mark(p, PVV_MARK_PRUNE0, st)) return e;
+    sa.lead = lead;
+    // round 4: the second launch's items own a RUN of an (image, keypoint)'s remaining chunks and keep eliminating inside it
+    // (count_filter_runs.hpp); one generation of blocks, the run length adapts the item count to it.  (Round 3's
+    // one-chunk items stay reachable in tuning builds: PVV_FILTER_OLD=1.)
+    // With runs of ONE chunk the new items only add their elimination step to round 3's (+2 % per call at config 3, B = 16 / 24):
+    // when the images the last call of this shape reported (the stage hint: AUTO only) predict that, round 3's kernel runs.
+    const long long rest = p->count_kernel == PVV_COUNT_AUTO ? stage_hint_rest_chunks(p, st, stage_rest_of(FIRST)) : -1;
+    const bool runs = rest < 0 || rest * p->K >= 2ll * a.target_filter;
+    if (tuning_int("PVV_FILTER_OLD", runs ? 0 : 1) == 0) {
+        hipLaunchKernelGGL(k_count_filter_runs<FIRST>, dim3(tuning_int("PVV_GRID_PER_CU_FILTER", 5) * num_cus()), dim3(kBlock), 0, st, coords, dirs,
+                           hyps, counts, tn, p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, a.target_filter, tuning_int("PVV_RUN_R", 0), sa);
+        return check_launch("k_count_filter_runs");
+    }
+    hipLaunchKernelGGL((k_count_bf16<kCountFilter, FIRST>), dim3(a.per_cu_filter * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
+                       p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, a.target_filter, a.dbg, sa);
+    return check_launch("k_count_bf16<filter>");
+}
+
 int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, bool staged)
 {
     // persistent blocks per CU (5 are resident): every block builds the item table once, so few blocks are better when
@@ -440,46 +503,16 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
                            p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target, dbg, StageArgs{nullptr, nullptr});
         return check_launch("k_count_bf16");
     }
-    // ransac_voting_layer_v3, staged: count a spread quarter of the chunks for every hypothesis, count four leaders
-    // exactly over the rest (k_lead), then the rest only for the hypotheses that can still reach the best leader
-    int *lead = (int *)(ws + L.lead);
-    StageArgs sa;
-    sa.lead = nullptr;
-    sa.any_staged = lead + (size_t)p->B * p->K * 8;
-    sa.miss = (int *)(ws + L.miss);
-    hipLaunchKernelGGL(k_count_bf16<kCountFirst>, dim3(per_cu_first * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
-                       p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target_first, dbg, sa);
-    if (int e = check_launch("k_count_bf16<first>")) return e;
-    if (int e = mark(p, PVV_MARK_STAGE0, st)) return e;
-    LeadArgs la;
-    la.tn_arr = tn; la.coords = coords; la.dirs = dirs; la.hyps = hyps; la.counts = counts; la.lead = lead;
-    la.K = p->K; la.hn = p->hn; la.cap = p->cap;
-    la.kappa = fc.kappa; la.beta = 2.f * fc.beta2; la.eps = 2.f * fc.eps0;
-    la.any_staged = sa.any_staged;
-    // shares per (image, keypoint): the largest power of two <= 16 that keeps the grid within one generation of blocks
-    // (8 per CU)
-    la.nsplit = 16;
-    while (la.nsplit > 1 && (long long)p->B * p->K * la.nsplit > 8ll * num_cus()) la.nsplit >>= 1;
-    la.nsplit = tuning_int("PVV_LEAD_SPLIT", la.nsplit);
-    hipLaunchKernelGGL(k_lead, dim3(p->K * la.nsplit, p->B), dim3(kBlock), 0, st, la);
-    if (int e = check_launch("k_lead")) return e;
-    if (int e = mark(p, PVV_MARK_PRUNE0, st)) return e;
-    sa.lead = lead;
-    // round 4: the second launch's items own a RUN of an (image, keypoint)'s remaining chunks and keep eliminating inside it
-    // (count_filter_runs.hpp); one generation of blocks, the run length adapts the item count to it.  (Round 3's
-    // one-chunk items stay reachable in tuning builds: PVV_FILTER_OLD=1.)
-    // With runs of ONE chunk the new items only add their elimination step to round 3's (+2 % per call at config 3, B = 16 / 24):
-    // when the images the last call of this shape reported (the stage hint: AUTO only) predict that, round 3's kernel runs.
-    const long long rest = p->count_kernel == PVV_COUNT_AUTO ? stage_hint_rest_chunks(p, st) : -1;
-    const bool runs = rest < 0 || rest * p->K >= 2ll * target_filter;
-    if (tuning_int("PVV_FILTER_OLD", runs ? 0 : 1) == 0) {
-        hipLaunchKernelGGL(k_count_filter_runs, dim3(tuning_int("PVV_GRID_PER_CU_FILTER", 5) * num_cus()), dim3(kBlock), 0, st, coords, dirs,
-                           hyps, counts, tn, p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target_filter, tuning_int("PVV_RUN_R", 0), sa);
-        return check_launch("k_count_filter_runs");
-    }
-    hipLaunchKernelGGL(k_count_bf16<kCountFilter>, dim3(per_cu_filter * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
-                       p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target_filter, dbg, sa);
-    return check_launch("k_count_bf16<filter>");
+    // ransac_voting_layer_v3, staged: count a spread part of the chunks for every hypothesis, bound the winner's count from
+    // below through two leaders (k_lead), then the rest only for the hypotheses that can still reach that bound.  The first
+    // stage is a QUARTER of the chunks, or an EIGHTH when the problem is so large that the second launch's runs are long
+    // (measured, one-process A/B of whole calls: -5 % at config 3 / B = 96, -4 % at B = 128, -9 % on config 5 / B = 16, -5 % at its
+    // B = 8; +2.5 % at config 3 / B = 64: log2(work / 2.26e10) >= 2.25)
+    StagedLaunch sl;
+    sl.p = p; sl.ws = ws; sl.L = &L; sl.st = st; sl.fc = fc; sl.dbg = dbg;
+    sl.per_cu_first = per_cu_first; sl.per_cu_filter = per_cu_filter; sl.target_first = target_first; sl.target_filter = target_filter;
+    const bool eighth = tuning_int("PVV_STAGE_EIGHTH", (double)p->B * p->K * p->hn * p->H * p->W >= 2.26e10 * 4.757 ? 1 : 0) != 0;
+    return eighth ? launch_staged<kStageFirstEighth>(sl) : launch_staged<kStageFirst>(sl);
 }
 
 CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)

@@ -260,8 +260,10 @@ def test_count_kernel_isa_guard(tmp_path):
     subprocess.check_call([hipcc, *flags, "-I" + b.INCLUDE, "-I" + b.CSRC, "-S", "--cuda-device-only", "-o", str(out),
                            os.path.join(b.CSRC, "pvnet_vote.hip")], stderr=subprocess.DEVNULL)
     asm = out.read_text()
-    # full, staged-first, round 3's staged-filter, round 4's run-owning filter launch
-    for frag in ("k_count_bf16ILi0E", "k_count_bf16ILi1E", "k_count_bf16ILi2E", "k_count_filter_runs"):
+    # full, staged-first, round 3's staged-filter, round 4's run-owning filter launch -- the staged ones for both chunk
+    # schedules (first stage = a quarter of the chunks: mask 0x22 = 34; an eighth: 2)
+    for frag in ("k_count_bf16ILi0ELj34E", "k_count_bf16ILi1ELj34E", "k_count_bf16ILi1ELj2E", "k_count_bf16ILi2ELj34E",
+                 "k_count_bf16ILi2ELj2E", "k_count_filter_runsILj34E", "k_count_filter_runsILj2E"):
         body, meta = _kernel_isa(asm, frag)
         lines = body.splitlines()
         mf = [i for i, l in enumerate(lines) if "v_mfma_f32_32x32x16_bf16" in l]

@@ -50,10 +50,13 @@ def main():
     ap.add_argument("--mode", default="count", choices=["count", "v3", "decode"],
                     help="count: re-launches of the inlier-count kernel; v3: whole pvv_ransac_voting_v3 calls; decode: whole "
                          "pvv_decode_keypoint_v3 calls on seg logits + the planar vertex view (one [B,2+2K,H,W] tensor, resnet18.py:93)")
+    ap.add_argument("--outlier", type=float, default=None, help="fraction of foreground pixels with a random direction")
     ap.add_argument("--rotate", type=int, default=1, help="v3 mode: cycle over this many distinct device-resident batches (cold caches)")
     a = ap.parse_args()
     synth = _synth()
     cfg = dict(synth.CONFIGS[a.config])
+    if a.outlier is not None:
+        cfg["outlier"] = a.outlier
     B = a.batch or cfg["B"]
     hn = a.hn or cfg["hn"]
     dev = torch.device("cuda:0")
