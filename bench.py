@@ -453,7 +453,10 @@ def main():
         call_pmc = load_profile("call_pmc.json")
         if not call_pmc or call_pmc.get("workload") != wl:
             call_pmc = None
-        pass_names = ("k_count_bf16<1>", "k_lead", "k_count_bf16<2>") if staged_path else ("k_count_bf16<0>",)
+        # the staged pass's second launch: k_count_filter_runs (round 4: runs of chunks) -- or round 3's k_count_bf16<2> where the
+        # library predicts one-chunk runs; the profile says which one this workload ran
+        second = "k_count_bf16<2>" if call_pmc and "k_count_filter_runs" not in call_pmc["kernels"] else "k_count_filter_runs"
+        pass_names = ("k_count_bf16<1>", "k_lead", second) if staged_path else ("k_count_bf16<0>",)
         call_names = ("k_tile_scan", "k_compact_hyp") + pass_names + ("k_select_refit", "k_finalize_v3")
 
         def pmc_sum(names, field):
@@ -486,7 +489,7 @@ def main():
         # the contract figure of rounds 1-3, kept for continuity: dense-field bytes / duration of the count pass alone
         roofline_contract = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac_not_a_bound": round(achieved / HBM_PEAK_GBS, 4), "traffic": pass_traffic, "traffic_source": pmc_src,
-                    "kernel": ("inlier-count pass: k_count_bf16<first> + k_lead + k_count_bf16<filter>" if staged_path else "k_count_bf16"),
+                    "kernel": ("inlier-count pass: " + " + ".join(pass_names)) if staged_path else "k_count_bf16",
                     "kernel_ms_avg": round(k_avg_ms, 4), "kernel_ms_median": round(k_med_ms, 4),
                     "kernel_ms_how": "HIP events recorded at the stage boundaries INSIDE full calls on the launch stream (pvv_problem.ev_marks), "
                                      "30 calls cycling over the rotating batches -- the sample rocprofv3 --kernel-trace sees",

@@ -1,12 +1,15 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): kernel-trace stats + PMC passes of the default bench workload.
 # Output lands in gpurun_out/prof_<tag>/ ; copy the summaries you want judged into profiles/.
+# Round 4: the profiled command runs ONE problem size per kernel (--no-side-legs: no noisy-field / un_pnp / decode legs);
+# the estimate's count pass (4096 hypotheses) and the fused decode get their own, small passes (tools/prof_side.py).
 set -u
 TAG=${1:-run}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-two-stream"
+BENCH="python $PWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-two-stream --no-side-legs"
+SIDE="python $PWD/tools/prof_side.py"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/bench_trace.log 2>&1
 # separate counter passes (never combined with tracing domains)
@@ -14,5 +17,12 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLE
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC -d $OUT/pmc2 -o pmc2 --output-format csv -- $BENCH > $OUT/bench_pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 --output-format csv -- $BENCH > $OUT/bench_pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc4 --output-format csv -- $BENCH > $OUT/bench_pmc4.log 2>&1
-find $OUT -name "*.csv" | head -30
-find $OUT -name "*kernel_stats*.csv" -exec cat {} \;
+# the side paths: v3 + estimate (un_pnp) and the fused decode on the real caller's layout, 12 calls each
+mkdir -p $OUT/side
+rocprofv3 --kernel-trace --stats -d $OUT/side/trace -o trace --output-format csv -- $SIDE > $OUT/side_trace.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES -d $OUT/side/pmc1 -o pmc1 --output-format csv -- $SIDE > $OUT/side_pmc1.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE -d $OUT/side/pmc2 -o pmc2 --output-format csv -- $SIDE > $OUT/side_pmc2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/side/pmc3 -o pmc3 --output-format csv -- $SIDE > $OUT/side_pmc3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/side/pmc4 -o pmc4 --output-format csv -- $SIDE > $OUT/side_pmc4.log 2>&1
+find $OUT -name "*.csv" | head -40
+find $OUT/trace -name "*kernel_stats*.csv" -exec cat {} \;

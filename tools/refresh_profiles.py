@@ -18,8 +18,11 @@ else:      # tools/evidence.sh summarised on the GPU box (the raw output does no
 
 
 def short(n):
-    m = re.search(r"(k_[a-z_0-9]+(<\d+>)?)", n)
-    return m.group(1) if m else None
+    """this repository's kernel name without its template arguments -- except the count kernel's MODE (k_count_bf16<1>)"""
+    m = re.search(r"(k_[a-z_0-9]+)(<\s*(\d+)[^>]*>)?", n)
+    if not m:
+        return None
+    return "%s<%s>" % (m.group(1), m.group(3)) if m.group(1) == "k_count_bf16" and m.group(3) else m.group(1)
 
 
 rows = list(csv.DictReader(open(stats_csv)))
@@ -30,8 +33,9 @@ with open(os.path.join(ROOT, "profiles", TAG + "_kernel_stats.csv"), "w") as o:
         if short(r["Name"]):
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 summ = json.load(open(tmp))
-# the count pass of the profiled workload: one k_count_bf16<0> launch, or -- staged -- <1> + k_lead + <2>
-pass_kernels = [k for k in ("k_count_bf16<1>", "k_lead", "k_count_bf16<2>") if k in summ["pmc"]] or ["k_count_bf16<0>"]
+# the count pass of the profiled workload: one k_count_bf16<0> launch, or -- staged -- <1> + k_lead + the second launch
+# (round 4: k_count_filter_runs; round 3: k_count_bf16<2>)
+pass_kernels = [k for k in ("k_count_bf16<1>", "k_lead", "k_count_filter_runs", "k_count_bf16<2>") if k in summ["pmc"]] or ["k_count_bf16<0>"]
 def kb(kern, name):
     return summ["pmc"].get(kern, {}).get(name, {}).get("main_mean", 0.0)
 fetch = sum(kb(k, "FETCH_SIZE") for k in pass_kernels)
@@ -57,6 +61,50 @@ for kern, fmul in (("k_tile_scan", 2.0), ("k_compact_hyp", 1.0)):
     front[kern] = {"FETCH_SIZE_KB": kb(kern, "FETCH_SIZE"), "WRITE_SIZE_KB": kb(kern, "WRITE_SIZE"), "fetch_correction": fmul,
                    "hbm_bytes_per_launch": int((fmul * kb(kern, "FETCH_SIZE") + kb(kern, "WRITE_SIZE")) * 1024)}
 json.dump(front, open(os.path.join(ROOT, "profiles", "front_kernels_pmc.json"), "w"), indent=1)
+
+# ---- profiles/call_pmc.json (round 4): every kernel of ONE ransac_voting_layer_v3 call of the bench workload, per launch --
+# HBM bytes (FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes, see `fetch_correction`), issued VALU instructions, VALU
+# busy -- and the same for the side paths (tools/prof_side.py: the estimate's 4096-hypothesis count kernel, the fused decode).
+# bench.py reads this file for roofline.traffic, roofline_valu and the estimate's block; it says the figures are static.
+WIDE_STREAMS = {"k_tile_scan": "8 B per lane, unit stride, read once: calibrated on the known byte count (B*H*W*8 of int64 mask) = 2.0 x FETCH_SIZE",
+                "k_stream_read": "16 B per lane streaming read: x2 (MI355X_MICROARCH.md, HBM)",
+                "k_tile_scan_seg2": "16 B per lane streaming read of two f32 planes: x2 (MI355X_MICROARCH.md, HBM); known byte count B*2*H*W*4"}
+
+
+def kernel_block(summary, kern):
+    def v(name):
+        return summary["pmc"].get(kern, {}).get(name, {}).get("main_mean", 0.0)
+    fmul = 2.0 if kern in WIDE_STREAMS else 1.0
+    gui, act = v("GRBM_GUI_ACTIVE"), v("SQ_ACTIVE_INST_VALU")
+    blk = {"FETCH_SIZE_KB": v("FETCH_SIZE"), "WRITE_SIZE_KB": v("WRITE_SIZE"), "fetch_correction": fmul,
+           "hbm_bytes": int((fmul * v("FETCH_SIZE") + v("WRITE_SIZE")) * 1024),
+           "SQ_INSTS_VALU": int(v("SQ_INSTS_VALU")), "SQ_ACTIVE_INST_VALU": int(act), "GRBM_GUI_ACTIVE": int(gui),
+           "valu_busy": round(act * 4 / 1024 / (gui / 8), 4) if gui else None,
+           "avg_us": summary.get("kernel_stats", {}).get(kern, {}).get("avg_us")}
+    if kern in WIDE_STREAMS:
+        blk["fetch_correction_why"] = WIDE_STREAMS[kern]
+    return blk
+
+
+call = {"workload": old.get("workload"), "round": TAG,
+        "command": "python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-two-stream --no-side-legs",
+        "how": "separate rocprofv3 --pmc passes of that command (tools/profile_bench.sh), per launch: the mean over the launches of the "
+               "bench batch; hbm_bytes = (fetch_correction x FETCH_SIZE + WRITE_SIZE) x 1024; valu_busy = SQ_ACTIVE_INST_VALU x 4 / 1024 "
+               "SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); gathers and atomics are taken x1.0, uncalibrated",
+        "kernels": {k: kernel_block(summ, k) for k in summ["pmc"]}}
+side_path = os.path.join(fin, "prof_side_summary.json")
+if os.path.exists(side_path):
+    side = json.load(open(side_path))
+    json.dump(side, open(os.path.join(ROOT, "profiles", TAG + "_side_summary.json"), "w"), indent=1)
+    if "k_count_bf16<0>" in side.get("pmc", {}):
+        call["estimate_4096"] = dict(kernel_block(side, "k_count_bf16<0>"), kernel="k_count_bf16<0> at 4096 hypotheses (estimate_voting_distribution_with_mean, B = 64)",
+                                     command="python tools/prof_side.py")
+    call["decode_fused"] = {k: kernel_block(side, k) for k in ("k_tile_scan_seg2", "k_mask_from_lists", "k_compact_hyp") if k in side.get("pmc", {})}
+json.dump(call, open(os.path.join(ROOT, "profiles", "call_pmc.json"), "w"), indent=1)
+for extra_name in ("staged_ab.json", "staged_ab_outliers.json", "ab_filter_runs.txt"):
+    if os.path.exists(os.path.join(fin, extra_name)):
+        import shutil
+        shutil.copy(os.path.join(fin, extra_name), os.path.join(ROOT, "profiles", TAG + "_" + extra_name))
 for a, b in (("bench_default", TAG + "_bench_default"), ("bench_extras", TAG + "_bench_extras"),
              ("bench_torchrun1", TAG + "_bench_torchrun_1rank"), ("bench_under_rocprof", TAG + "_bench_under_rocprof")):
     if not os.path.exists(os.path.join(fin, a + ".json")):

@@ -11,8 +11,11 @@ from collections import defaultdict
 
 
 def short(n):
-    m = re.search(r"(k_[a-z_0-9]+(<\d+>)?)", n)
-    return m.group(1) if m else None
+    """this repository's kernel name without its template arguments -- except the count kernel's MODE (k_count_bf16<1>)"""
+    m = re.search(r"(k_[a-z_0-9]+)(<\s*(\d+)[^>]*>)?", n)
+    if not m:
+        return None
+    return "%s<%s>" % (m.group(1), m.group(3)) if m.group(1) == "k_count_bf16" and m.group(3) else m.group(1)
 
 
 def main():
