@@ -196,7 +196,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 //      arrays reserve cap rows -- and masked below), the survivors' hypotheses (cached: every chunk re-reads them).
                 //      (Requesting the run's FIRST chunk together with the counters -- one memory round trip, like round 3's
                 //      items, the survivors staged while they are compacted -- was built and measured: +1.5 ... 3 % per call at
-                //      every batch size, 28 B of scratch; so was requesting the next chunk behind the matrix-core loop: +-0.)
+                //      every batch size, 28 B of scratch; so was requesting the NEXT chunk's pixels behind the matrix-core loop, beside
+                //      the elimination step's atomics (twice, before and after the counters became shared): +0.5 ... 1 %, 24 B of scratch.)
                 const float2 org = crd[pb];
                 float2 pc[2], pd[2];
 #pragma unroll
