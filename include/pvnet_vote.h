@@ -30,7 +30,7 @@ extern "C" {
 #define PVV_E_WORKSPACE (-2) /* workspace smaller than pvv_workspace_bytes() */
 
 /* ABI version of this header; pvv_abi_version() must return the same. */
-#define PVV_ABI_VERSION 6
+#define PVV_ABI_VERSION 7
 
 int pvv_abi_version(void);
 const char *pvv_last_error(void);
@@ -150,6 +150,15 @@ typedef struct pvv_problem {
  * against.  (Round 1 selected this with an environment variable; the library now reads no environment.) */
 #define PVV_COUNT_AUTO 0
 #define PVV_COUNT_EXACT 1
+/* ABI v7 (round 4) -- no signature changed, three behaviours did:
+ *  - the staged count's second launch owns RUNS of an (image, keypoint)'s remaining chunks and eliminates cooperatively
+ *    through per-hypothesis miss counters (count_filter_runs.hpp): the workspace reserves them, pvv_workspace_bytes() grew;
+ *  - pvv_rerun_count_kernel re-runs the pass in stages only for an explicit PVV_COUNT_STAGED (see there);
+ *  - pvv_decode_keypoint_v3 / pvv_decode_keypoint_un_pnp on a two-class seg in two contiguous planes may write d_mask_out
+ *    from a second, library-owned HIP stream (one per device, created on first use) that is forked from and joined back
+ *    into `stream` inside the call: for the caller everything stays ordered on `stream`.  Not used while `stream` is being
+ *    captured into a graph. */
+
 /* ABI v6.  ransac_voting_layer_v3 keeps only the arg-max of the counts (P:160-167), so pvv_ransac_voting_v3 /
  * pvv_decode_keypoint_v3 may count in STAGES: every hypothesis over a spread quarter of the pixels, then only the
  * hypotheses that can still reach a lower bound of a leader's full count over the rest (k_lead, count_prune.hpp).  Winner,

@@ -31,7 +31,7 @@ def test_cabi_library_exports_every_declared_symbol():
 
 def test_cabi_version_and_cap_and_validation():
     L = capi.load()
-    assert L.pvv_abi_version() == 6
+    assert L.pvv_abi_version() == 7
     assert L.pvv_default_cap(480, 640, 30000) == 30000 + int(8 * 30000 ** 0.5) + 64
     assert L.pvv_default_cap(128, 128, 30000) == 128 * 128
     p = capi.Problem()
@@ -54,7 +54,7 @@ def test_extension_module_surface_matches_reference(pkg):
     for name in ("generate_hypothesis", "voting_for_hypothesis", "generate_hypothesis_vanishing_point",
                  "voting_for_hypothesis_vanishing_point"):                  # ransac_voting.cpp:102-107
         assert callable(getattr(ext, name))
-    assert ext.abi_version == 6
+    assert ext.abi_version == 7
     import lib.csrc.ransac_voting.ransac_voting as ref_path                  # ransac_voting_gpu.py:2
     assert ref_path.generate_hypothesis is ext.generate_hypothesis
 
