@@ -680,6 +680,13 @@ int run_scan(const pvv_problem *p, const Front &f, char *ws, const Layout &L, hi
 // Not used while the caller's stream is capturing (no stream or event is created under capture) or when the stream
 // belongs to a device that is not current.
 // ---------------------------------------------------------------------------------------------
+// Both streams are on ONE device: the events between them need no system-scope fence (host / other devices do not look at
+// what they order), only the agent-scope release every kernel ends with.
+#ifdef PVV_SIDE_EVENT_SYSTEM_FENCE                                    // (tuning builds: A/B of the event flags)
+constexpr unsigned kSideEventFlags = hipEventDisableTiming;
+#else
+constexpr unsigned kSideEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
+#endif
 struct SideStream {
     hipStream_t st = nullptr;
     hipEvent_t fork[8] = {}, join[8] = {};
@@ -704,8 +711,8 @@ SideStream *side_get(hipStream_t st)
         g->tried = true;
         bool ok = hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking) == hipSuccess;
         for (int i = 0; ok && i < 8; ++i)
-            ok = hipEventCreateWithFlags(&g->fork[i], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&g->join[i], hipEventDisableTiming) == hipSuccess;
+            ok = hipEventCreateWithFlags(&g->fork[i], kSideEventFlags) == hipSuccess &&
+                 hipEventCreateWithFlags(&g->join[i], kSideEventFlags) == hipSuccess;
         if (!ok) (void)hipGetLastError();
         g->ok = ok;
     }
