@@ -16,7 +16,7 @@ K exchanges complete inside the timed region: the last one is ordered before the
 
 Workload = BASELINE config 3: 480x640, K=9, 512 hypotheses, ~2 % foreground, 64 images.
   N = 1   the 64 images on one GPU (the configuration the roofline target is quoted on);
-  N > 1   WEAK scaling (default, ``"scaling": "weak"``): 64 images PER GPU, global batch 64 N -- every rank decodes the
+  N > 1   WEAK scaling (default, ``"scaling": "weak"``, and the metric's NAME says so: ADVICE r3): 64 images PER GPU, global batch 64 N -- every rank decodes the
           batch its own network produced and the ranks exchange the keypoints: images are independent units, the path
           shards with no data-path collective.  ``--scaling strong`` is BASELINE config 3 read literally ("batch=64
           sharded over 8xMI355X"): the same 64 images in contiguous shards of 64/N (clean_pvnet_amd.dist.shard_bounds).
@@ -26,20 +26,23 @@ Steps cycle over --rotate (default 3) distinct device-resident batches, so that 
 the L2 holds a step's inputs from the step before.
 
 One JSON line on rank 0.  Besides the contract fields it carries
+  value_at_rho_0.90  the same call on fields with 9.5 % outlier pixels (the staged count's gain depends on clean fields)
   step_ms          per-step HIP events on the launch stream: median / p10 / p90 (the contract's ``ms_per_step`` is the wall
                    clock over the K steps, barrier + synchronize on both sides, max over ranks)
-  roofline         the inlier-count PASS (dominant: k_count_bf16, or -- staged -- its two launches + k_lead): SURVEY 8d's
-                   dense-field bytes / its average duration, from HIP events the library records at the stage boundaries
-                   INSIDE full calls (pvv_problem.ev_marks); ``traffic`` from the committed PMC file (static)
-  roofline_call    the same bytes / ms_per_step: the whole call against the dense field
+  roofline         the WHOLE CALL against HBM: SURVEY 8d's dense-field bytes / ms_per_step (bounded: the call consumes the
+                   field once); ``traffic`` = the bytes its kernels really move (profiles/call_pmc.json, static), ``traffic_frac``
+  roofline_contract_count_pass   rounds 1-3's contract figure (dense-field bytes / the count pass): not a bound, kept for continuity
   roofline_scan, roofline_compact   the two HBM-facing kernels against what they move, and against the box's own
                    streaming-read rate (pvv_stream_read_probe, measured in this run)
-  roofline_valu    the count pass against fp32 VALU issue, in equivalent evaluations of a full pass
-  cpu_baseline     the oracle (oracle/vote_oracle.c) on the host: one thread and OpenMP over the cores, a bounded sample of
-                   the timed images -- and the SAME images with the SAME index pairs through the GPU path, cross-checked
-                   (winner counts equal, means within the contract); rank 0, N = 1 only
-  extra            per-kernel durations inside calls, rank / shard bookkeeping; with --extras also B=1 latency (config 2),
-                   v3 + estimate, the default path, decode
+  roofline_valu    the count pass on ISSUED VALU instructions (SQ_INSTS_VALU, static) / its duration inside calls (live) against
+                   1024 SIMDs x max clock / 2 cycles; ``busy_frac`` = SQ_ACTIVE_INST_VALU x 4 / SIMD cycles from the counters
+  cpu_baseline     the oracle (oracle/vote_oracle.c) on the host: one thread and OpenMP over the cores (the thread probe's table
+                   included), a bounded sample of the timed images -- and the SAME images with the SAME index pairs through the
+                   GPU path, cross-checked (winner counts equal, means within the contract); rank 0, N = 1 only
+  extra            per-kernel durations inside calls, rank / shard bookkeeping, the un_pnp path (v3 + estimate, two calls and one
+                   fused pass, the estimate's count pass with its VALU block), the fused decode on the real caller's layout,
+                   predicted_8gpu (from the tracked one-GPU profile; unmeasured); with --extras also B=1 latency (config 2),
+                   the default path, uncertainty PnP, ADD-S
 """
 import argparse
 import json
@@ -593,6 +596,10 @@ def main():
                                       global_batch, B, len(batches)),
                        "batch_per_gpu": B, "global_batch": global_batch, "H": H, "W": W, "K": K, "hn": hn,
                        "inlier_thresh": thresh,
+                       "arithmetic": "IEEE binary32, one rounding per source-level operation, NO fused multiply-add: inlier counts are "
+                                     "bit-exact against the reference's kernel compiled without contraction (oracle/_ref, tests/test_ref_pin.py); "
+                                     "nvcc's default contraction moves <= 1e-5 of the reference's own inlier decisions (libref_ransac_voting_fma.so) -- "
+                                     "unverifiable without nvcc; normal equations in binary64 (DESIGN.md 3)",
                        "parallelism": ("x%d GPUs, %d images per GPU (weak scaling: global batch %d)" % (world, B, global_batch)) if weak
                                       else ("batch-sharded x%d (strong scaling: %d images in total)" % (world, global_batch))},
             "step_ms": {"median": round(pct(per_step, 0.5), 4), "p10": round(pct(per_step, 0.1), 4),

@@ -7,6 +7,32 @@ import csv, glob, json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof, fin = sys.argv[1], sys.argv[2]
 TAG = sys.argv[3] if len(sys.argv) > 3 else "r02"
+
+
+def copy_bench_lines():
+    for a, b in (("bench_default", TAG + "_bench_default"), ("bench_extras", TAG + "_bench_extras"),
+                 ("bench_torchrun1", TAG + "_bench_torchrun_1rank"), ("bench_under_rocprof", TAG + "_bench_under_rocprof"),
+                 ("bench_driver_command", TAG + "_bench_driver_command")):
+        if not os.path.exists(os.path.join(fin, a + ".json")):
+            continue
+        lines = [l for l in open(os.path.join(fin, a + ".json")) if l.startswith("{")]
+        if lines:
+            json.dump(json.loads(lines[-1]), open(os.path.join(ROOT, "profiles", b + ".json"), "w"), indent=1)
+
+
+if "--bench-only" in sys.argv:      # tools/evidence_bench.sh: the lines printed with the committed profiles/call_pmc.json in place
+    copy_bench_lines()
+    if os.path.exists(os.path.join(fin, "kernel_stats_raw.csv")):
+        rows = list(csv.DictReader(open(os.path.join(fin, "kernel_stats_raw.csv"))))
+        with open(os.path.join(ROOT, "profiles", TAG + "_kernel_stats_bench_rerun.csv"), "w") as o:
+            w = csv.writer(o)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
+            for r in rows:
+                m = re.search(r"(k_[a-z_0-9]+)(<\s*(\d+)[^>]*>)?", r["Name"])
+                if m:
+                    n = "%s<%s>" % (m.group(1), m.group(3)) if m.group(1) == "k_count_bf16" and m.group(3) else m.group(1)
+                    w.writerow([n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+    sys.exit(0)
 tmp = os.path.join(ROOT, "profiles", TAG + "_summary.json")
 if os.path.isdir(os.path.join(prof, "trace")):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_prof.py"), prof, "--json", tmp],
@@ -105,12 +131,7 @@ for extra_name in ("staged_ab.json", "staged_ab_outliers.json", "ab_filter_runs.
     if os.path.exists(os.path.join(fin, extra_name)):
         import shutil
         shutil.copy(os.path.join(fin, extra_name), os.path.join(ROOT, "profiles", TAG + "_" + extra_name))
-for a, b in (("bench_default", TAG + "_bench_default"), ("bench_extras", TAG + "_bench_extras"),
-             ("bench_torchrun1", TAG + "_bench_torchrun_1rank"), ("bench_under_rocprof", TAG + "_bench_under_rocprof")):
-    if not os.path.exists(os.path.join(fin, a + ".json")):
-        continue
-    line = [l for l in open(os.path.join(fin, a + ".json")) if l.startswith("{")][-1]
-    json.dump(json.loads(line), open(os.path.join(ROOT, "profiles", b + ".json"), "w"), indent=1)
+copy_bench_lines()
 if os.path.exists(os.path.join(fin, "configs.json")):
     json.dump(json.load(open(os.path.join(fin, "configs.json"))), open(os.path.join(ROOT, "profiles", TAG + "_configs.json"), "w"), indent=1)
 for extra in glob.glob(os.path.join(fin, "gaps_*.json")):
