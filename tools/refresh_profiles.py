@@ -105,7 +105,9 @@ def kernel_block(summary, kern):
     blk = {"FETCH_SIZE_KB": v("FETCH_SIZE"), "WRITE_SIZE_KB": v("WRITE_SIZE"), "fetch_correction": fmul,
            "hbm_bytes": int((fmul * v("FETCH_SIZE") + v("WRITE_SIZE")) * 1024),
            "SQ_INSTS_VALU": int(v("SQ_INSTS_VALU")), "SQ_ACTIVE_INST_VALU": int(act), "GRBM_GUI_ACTIVE": int(gui),
-           "valu_busy": round(act * 4 / 1024 / (gui / 8), 4) if gui else None,
+           # (two counter passes: a saturated kernel can read a few % above 1; the raw ratio is kept beside the capped one)
+           "valu_busy": round(min(1.0, act * 4 / 1024 / (gui / 8)), 4) if gui else None,
+           "valu_busy_raw": round(act * 4 / 1024 / (gui / 8), 4) if gui else None,
            "avg_us": summary.get("kernel_stats", {}).get(kern, {}).get("avg_us")}
     if kern in WIDE_STREAMS:
         blk["fetch_correction_why"] = WIDE_STREAMS[kern]
@@ -125,7 +127,7 @@ if os.path.exists(side_path):
     if "k_count_bf16<0>" in side.get("pmc", {}):
         call["estimate_4096"] = dict(kernel_block(side, "k_count_bf16<0>"), kernel="k_count_bf16<0> at 4096 hypotheses (estimate_voting_distribution_with_mean, B = 64)",
                                      command="python tools/prof_side.py")
-    call["decode_fused"] = {k: kernel_block(side, k) for k in ("k_tile_scan_seg2", "k_mask_from_lists", "k_compact_hyp") if k in side.get("pmc", {})}
+    call["decode_fused"] = {k: kernel_block(side, k) for k in ("k_tile_scan_seg2", "k_mask_from_lists") if k in side.get("pmc", {})}
 json.dump(call, open(os.path.join(ROOT, "profiles", "call_pmc.json"), "w"), indent=1)
 for extra_name in ("staged_ab.json", "staged_ab_outliers.json", "ab_filter_runs.txt"):
     if os.path.exists(os.path.join(fin, extra_name)):
