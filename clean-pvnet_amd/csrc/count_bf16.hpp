@@ -141,7 +141,20 @@ struct StageArgs {
                           // when none is (a batch of small masks then pays two empty launches, not two table builds)
     int *miss;            // k_count_filter_runs: [B,K,hn] misses proven so far among the pixels the first launch did not count
                           // (zeroed by k_compact_hyp; count_filter_runs.hpp)
+    int sub_tenth;        // 1: the caller is estimate_voting_distribution_with_mean, which weighs every hypothesis whose ratio is
+                          // within 0.1 of the best (P:262-264): the elimination bound is lowered accordingly (stage_bound)
 };
+
+// The count a hypothesis must still be able to reach to matter.  ransac_voting_layer_v3 keeps the arg-max: L* itself.  The
+// estimate zeroes every ratio below  max ratio - 0.1  in binary32 (k_covariance: thr = fl(fl(mx)/fl(tn)) - 0.1f, r = fl(c / tn),
+// r < thr -> 0): a hypothesis whose full count is below  L* - 0.1 tn - margin  has weight zero with its full count and with any
+// partial count (r is monotone in c), so it may be dropped.  margin: 0.1f = 0.1000000015 and three binary32 roundings of
+// ratios <= 1 are < 4e-7 in ratio units = tn * 4e-7 counts; ceil(tn / 10) + 2 + tn / 2^20 covers both for every tn.
+__device__ __forceinline__ int stage_bound(int lstar, int tn, int sub_tenth)
+{
+    if (sub_tenth && lstar >= 0) lstar -= (tn + 9) / 10 + 2 + (tn >> 20);
+    return lstar;
+}
 
 // chunks with a residue in `mask` among the first n chunks, and the j-th of them (residues present in a last, partial
 // period are a prefix of the sorted residues, so the j-th chunk does not depend on n)
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             int full = lead_p >= 0 ? lead_p + lead_r : -1;
             full = max(full, PVV_DPP(full, full, 0xB1, 0xf, false));   // quad_perm [1,0,3,2]
             full = max(full, PVV_DPP(full, full, 0x4E, 0xf, false));   // quad_perm [2,3,0,1]: lanes 0-3 hold the four leaders' maximum
-            lstar = __builtin_amdgcn_readfirstlane(full);
+            lstar = stage_bound(__builtin_amdgcn_readfirstlane(full), tn, sa.sub_tenth);
         }
         // kCountFilter: stage only the hypotheses of group g that can still reach L*, densely from slot 0 (order = pass,
         // wave, lane: irrelevant, the counter word carries the hypothesis' index within the group in its high half); pads

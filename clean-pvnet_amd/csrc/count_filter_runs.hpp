@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             int full = lead_p >= 0 ? lead_p + lead_r : -1;
             full = max(full, PVV_DPP(full, full, 0xB1, 0xf, false));   // quad_perm [1,0,3,2]
             full = max(full, PVV_DPP(full, full, 0x4E, 0xf, false));   // quad_perm [2,3,0,1]
-            lstar = __builtin_amdgcn_readfirstlane(full);
+            lstar = stage_bound(__builtin_amdgcn_readfirstlane(full), tn, sa.sub_tenth);
         }
 
         for (int g = 0; g < nhg;) {

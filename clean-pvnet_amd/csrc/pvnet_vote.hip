@@ -409,6 +409,7 @@ struct StagedLaunch {
     Bf16Consts fc;
     long long *dbg;
     int per_cu_first, per_cu_filter, target_first, target_filter;
+    int sub_tenth;       // 1: the estimate's bound (StageArgs.sub_tenth)
 };
 
 // the three launches of a staged count pass for one chunk schedule (FIRST = the residues mod 8 the first launch counts)
@@ -429,6 +430,7 @@ int launch_staged(const StagedLaunch &a)
     sa.lead = nullptr;
     sa.any_staged = lead + (size_t)p->B * p->K * 8;
     sa.miss = (int *)(ws + L.miss);
+    sa.sub_tenth = a.sub_tenth;
     hipLaunchKernelGGL((k_count_bf16<kCountFirst, FIRST>), dim3(a.per_cu_first * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
                        p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, a.target_first, a.dbg, sa);
     if (int e = check_launch("k_count_bf16<first>")) return e;
@@ -464,7 +466,7 @@ int launch_staged(const StagedLaunch &a)
     return check_launch("k_count_bf16<filter>");
 }
 
-int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, bool staged)
+int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, int staged /*0: full pass, 1: v3 in stages, 2: the estimate in stages*/)
 {
     // persistent blocks per CU (5 are resident): every block builds the item table once, so few blocks are better when
     // items are short (hn <= 512: one hypothesis group per item), more when they are long and uneven; several
@@ -511,6 +513,7 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     StagedLaunch sl;
     sl.p = p; sl.ws = ws; sl.L = &L; sl.st = st; sl.fc = fc; sl.dbg = dbg;
     sl.per_cu_first = per_cu_first; sl.per_cu_filter = per_cu_filter; sl.target_first = target_first; sl.target_filter = target_filter;
+    sl.sub_tenth = staged == 2 ? 1 : 0;
     const bool eighth = tuning_int("PVV_STAGE_EIGHTH", (double)p->B * p->K * p->hn * p->H * p->W >= 2.26e10 * 4.757 ? 1 : 0) != 0;
     return eighth ? launch_staged<kStageFirstEighth>(sl) : launch_staged<kStageFirst>(sl);
 }
@@ -532,12 +535,27 @@ CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
     return a;
 }
 
-// v3: the call is ransac_voting_layer_v3 proper (not the estimate, not the fused un_pnp pass), which may count in stages
-int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, bool v3)
+// The ESTIMATE in stages (round 4, measured and NOT taken by AUTO): estimate_voting_distribution_with_mean weighs every hypothesis
+// whose ratio lies within 0.1 of the best (P:262-264), so its count pass may drop what provably falls below that window
+// (stage_bound, count_bf16.hpp) when nobody asked for the counts themselves.  Covariances and PnP weights are bit-identical to the
+// full pass (tests/test_gpu_staged.py), a third of the hypothesis-tile work goes away (42 % of the hypotheses carry weight, 74 %
+// survive a quarter of the pixels, the pooled misses drop the rest as they go) -- and the call is SLOWER: 4096 hypotheses at
+// 480x640, K = 9: 1.60 vs 1.43 ms at B = 64 (1.49 with a quarter as first stage), 0.293 vs 0.221 at B = 8, 0.197 vs 0.053 at
+// B = 1; config 5's 2048 at B = 16: 1.72 vs 1.58 (tools/estimate_ab.py, profiles/r04_experiments.txt).  The full kernel builds a
+// chunk's pixel operands once for all eight hypothesis groups and runs VALU-saturated (busy 1.00); the second launch walks its
+// survivors in passes of 512 and rebuilds them per pass.  PVV_COUNT_STAGED still forces it (the tests' cross-check).
+bool est_stage_auto(const pvv_problem *) { return false; }
+
+// kind: 0 = the pass must deliver every count (the estimate when its counts are an output, the fused un_pnp pass);
+//       1 = ransac_voting_layer_v3 proper, which keeps the arg-max and may count in stages;
+//       2 = the estimate without a counts output, which may count in stages against its own bound
+int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, int kind)
 {
     if (p->ev_count_begin && hipEventRecord((hipEvent_t)p->ev_count_begin, st) != hipSuccess)
         return fail(PVV_E_ARG, "ev_count_begin is not a valid hipEvent_t");
-    const bool staged = v3 && may_stage(p) && L.lead != 0 && stage_hint_allows(p, st);
+    int staged = 0;
+    if (kind == 1 && may_stage(p) && L.lead != 0 && stage_hint_allows(p, st)) staged = 1;
+    if (kind == 2 && may_stage(p) && L.lead != 0 && (p->count_kernel == PVV_COUNT_STAGED || est_stage_auto(p))) staged = 2;
     const int e = use_bf16_count(p) ? launch_count_bf16(p, L, ws, st, staged) : launch_count(planar_count_args(p, L, ws), st);
     if (e) return e;
     if (p->ev_count_end && hipEventRecord((hipEvent_t)p->ev_count_end, st) != hipSuccess)
@@ -737,11 +755,11 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
               const int32_t *d_idxs, const float *d_selection, char *ws, const Layout &L,
               hipStream_t st, int32_t *d_tn, const float *d_seg = nullptr, int64_t *d_mask_out = nullptr,
               const int32_t *d_idxs2 = nullptr, int hn_first = -1, uint32_t stream_first = 1u, uint32_t stream_rest = 3u,
-              bool v3 = false)
+              int stage_kind = 0 /*launch_count_any's kind*/)
 {
     Front f = make_front(p, mode, d_mask, d_vertex, d_idxs, d_selection, ws, L, d_tn, d_seg, d_mask_out, d_idxs2,
                          hn_first, stream_first, stream_rest);
-    if (!v3) f.h.miss = nullptr;                                    // only a v3 call can count in stages: nothing else reads (or zeroes) them
+    if (stage_kind == 0) f.h.miss = nullptr;                        // a pass that cannot count in stages neither reads nor zeroes them
     if (int e = mark(p, PVV_MARK_BEGIN, st)) return e;
     hipStream_t side = nullptr;
     hipEvent_t join = nullptr;
@@ -773,7 +791,7 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
         if (int e = check_launch("k_mask_from_lists")) return e;
         if (deferred && hipEventRecord(join, side) != hipSuccess) return fail(PVV_E_ARG, "side stream: hipEventRecord failed");
     }
-    if (int e = launch_count_any(p, L, ws, st, v3)) return e;
+    if (int e = launch_count_any(p, L, ws, st, stage_kind)) return e;
     if (deferred && hipStreamWaitEvent(st, join, 0) != hipSuccess) return fail(PVV_E_ARG, "side stream: hipStreamWaitEvent failed");
     return mark(p, PVV_MARK_COUNT, st);
 }
@@ -864,7 +882,7 @@ PVV_EXPORT int pvv_ransac_voting_v3(const pvv_problem *p, const void *d_mask, co
     if (!d_out) return fail(PVV_E_ARG, "d_out is NULL");
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)d_workspace;
-    if (int e = run_front(p, 0, d_mask, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, nullptr, nullptr, nullptr, -1, 1u, 3u, true))
+    if (int e = run_front(p, 0, d_mask, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, nullptr, nullptr, nullptr, -1, 1u, 3u, 1))
         return e;
     return finish_v3(p, L, ws, d_out, d_win_counts, st);
 }
@@ -881,7 +899,7 @@ PVV_EXPORT int pvv_decode_keypoint_v3(const pvv_problem *p, const float *d_seg, 
     if (p->seg_classes < 1 || p->seg_classes > 256) return fail(PVV_E_ARG, "seg_classes must be in [1, 256]");
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)d_workspace;
-    if (int e = run_front(p, 0, nullptr, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, d_seg, d_mask_out, nullptr, -1, 1u, 3u, true))
+    if (int e = run_front(p, 0, nullptr, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, d_seg, d_mask_out, nullptr, -1, 1u, 3u, 1))
         return e;
     return finish_v3(p, L, ws, d_out, d_win_counts, st);
 }
@@ -898,7 +916,8 @@ PVV_EXPORT int pvv_estimate_voting_distribution(const pvv_problem *p, const void
     if (!d_mean || !d_cov) return fail(PVV_E_ARG, "d_mean / d_cov is NULL");
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)d_workspace;
-    if (int e = run_front(p, 1, d_mask, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, nullptr, nullptr, nullptr, -1, 3u, 3u)) return e;
+    // the counts are an output (d_counts): every one of them is needed; otherwise the pass may drop what cannot carry weight
+    if (int e = run_front(p, 1, d_mask, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, nullptr, nullptr, nullptr, -1, 3u, 3u, d_counts ? 0 : 2)) return e;
     hipLaunchKernelGGL(k_covariance, dim3(p->K, p->B), dim3(kBlock), 0, st,
                        (const int *)(ws + L.tn), (const float2 *)(ws + L.hyps),
                        (const int *)(ws + L.counts), (const float2 *)d_mean, d_cov, (float2 *)d_hyp,
@@ -962,7 +981,7 @@ PVV_EXPORT int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace, s
     // compares PARTIAL counts and therefore needs cleared counters.
     if (p && p->count_kernel == PVV_COUNT_STAGED && !zero_counts)
         return fail(PVV_E_ARG, "a staged count pass needs zero_counts = 1");
-    const bool v3 = p && p->count_kernel == PVV_COUNT_STAGED;
+    const int v3 = (p && p->count_kernel == PVV_COUNT_STAGED) ? 1 : 0;
     if (int e = validate(p)) return e;
     if (!d_workspace) return fail(PVV_E_ARG, "workspace is NULL");
     Layout L = make_layout(p);
