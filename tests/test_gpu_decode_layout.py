@@ -113,3 +113,59 @@ def test_deferred_mask_under_concurrent_streams_and_back_to_back_calls(synth, pk
     torch.cuda.synchronize()
     for i, m in outs:
         assert torch.equal(m, refs[i])
+
+
+def test_fused_decode_of_a_large_batch_inside_a_captured_graph(synth, pkg, gpu):
+    """While the caller's stream is being captured no side stream is used (nothing may be created or forked under capture): the
+    scan writes the mask itself.  The captured call replays with the same result as the eager one (which defers the mask)."""
+    from clean_pvnet_amd import ransac_voting as ext
+    B, H, W, K = 8, 480, 640, 3
+    seg, ver, _d = _network_output(synth, gpu, B, H, W, K, seed=77)
+    vertex = ver.permute(0, 2, 3, 1).view(B, H, W, K, 2)
+    eager = ext.decode_keypoint_v3(seg, vertex, 64, 0.99, 5, 30000, None, None, 5, ext.SINGULAR_REFERENCE)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            ext.decode_keypoint_v3(seg, vertex, 64, 0.99, 5, 30000, None, None, 5, ext.SINGULAR_REFERENCE)
+        with torch.cuda.graph(g, stream=s):
+            out = ext.decode_keypoint_v3(seg, vertex, 64, 0.99, 5, 30000, None, None, 5, ext.SINGULAR_REFERENCE)
+    for _ in range(3):
+        out[1].zero_()
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[1], torch.argmax(seg, 1)) and torch.equal(out[1], eager[1])
+    assert torch.equal(out[0], eager[0]) and torch.equal(out[2], eager[2])
+
+
+def test_deferred_mask_from_several_host_threads(synth, pkg, gpu):
+    """Four host threads, each with its own stream, decode different batches at the same time: one side stream per device and
+    a ring of events behind a mutex -- every call gets its own mask."""
+    import threading
+    from clean_pvnet_amd import ransac_voting as ext
+    B, H, W, K = 8, 480, 640, 2
+    cases = [_network_output(synth, gpu, B, H, W, K, seed=600 + i) for i in range(4)]
+    refs = [torch.argmax(c[0], 1) for c in cases]
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            seg, ver, _d = cases[i]
+            with torch.cuda.stream(st):
+                for _ in range(10):
+                    o = ext.decode_keypoint_v3(seg, ver.permute(0, 2, 3, 1).view(B, H, W, K, 2), 64, 0.99, 5, 30000, None, None, 3,
+                                               ext.SINGULAR_REFERENCE)
+                    if not torch.equal(o[1], refs[i]):
+                        errs.append(i)
+            st.synchronize()
+        except Exception as e:                                                  # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
