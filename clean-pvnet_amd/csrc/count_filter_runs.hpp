@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             const int gp0 = g;
             int ns = 0;
             __syncthreads();                                     // the previous pass / item is done with sCnt, sPrev, s_keep
-            for (; g < nhg && g - gp0 < 127; ++g) {
+            for (; g < nhg && g - gp0 < 63; ++g) {             // (a slot's hypothesis index relative to the pass: 15 bits)
                 bool keep[2];
                 int slack[2];
                 unsigned long long m[2];
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int i = tid + q * kBlock;
-                    hp[q] = i < ns ? hyp_k[gp0 * GH + (sCnt[i] >> 16)] : make_float2(0.f, 0.f);
+                    hp[q] = i < ns ? hyp_k[gp0 * GH + (int)((unsigned)sCnt[i] >> 16)] : make_float2(0.f, 0.f);
                 }
                 // ---- per pixel: the f32 unit normal (v_rsq_f32, see k_count_bf16) and the translated coordinates
                 float c1 = 0.f;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                     for (int ht = 0; ht < nht; ++ht) {
                         const int slot = ht * 32 + col;
                         if (slot >= nslot) continue;
-                        const float2 hq = hyp_p[sCnt[slot] >> 16];
+                        const float2 hq = hyp_p[(unsigned)sCnt[slot] >> 16];
                         int inl = 0;
                         for (int p = pb + wave * 2 + kslice; p < min(tn, pb + PC); p += 8) {
                             const float2 c = crd[p], d = dir_k[p];
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                         int inl = 8 * ntile_w - __popc(qs[0]) - __popc(qs[1]);   // sign bit set = not an inlier
                         if (__builtin_expect(flagged != 0u, 0) && __any((mb[0] | mb[1]) != 0u)) {
                             const int slot = ht * 32 + col;
-                            const float2 hq = slot < nslot ? hyp_p[sCnt[slot] >> 16] : make_float2(0.f, 0.f);
+                            const float2 hq = slot < nslot ? hyp_p[(unsigned)sCnt[slot] >> 16] : make_float2(0.f, 0.f);
                             do {
                                 const int jt = __builtin_ctz(flagged);
                                 flagged &= flagged - 1;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                         w[q] = 0;
                         if (i < ns) {
                             w[q] = sCnt[i];
-                            const int c = w[q] & 0xffff, h = gp0 * GH + (w[q] >> 16);
+                            const int c = w[q] & 0xffff, h = gp0 * GH + (int)((unsigned)w[q] >> 16);
                             const int dmiss = npx - (c - (int)sPrev[i]);
                             sPrev[i] = (unsigned short)c;
                             if (last) {
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             __syncthreads();
             for (int i = threadIdx.x; i < ns; i += kBlock) {
                 const int v = sCnt[i];
-                if (v & 0xffff) atomicAdd(&cnt_k[gp0 * GH + (v >> 16)], v & 0xffff);
+                if (v & 0xffff) atomicAdd(&cnt_k[gp0 * GH + (int)((unsigned)v >> 16)], v & 0xffff);
             }
         }
     }

@@ -330,6 +330,7 @@ def test_auto_follows_the_stage_hint(synth, pkg, gpu):
     (6, 480, 640, 3, 2048, 0.098, 0.0, "30 000 pixels per image, few items: runs of one chunk, four groups in one pass"),
     (12, 300, 400, 17, 700, 0.25, 0.15, "hn not a multiple of 32 or 512, 17 keypoints"),
     (112, 480, 640, 9, 512, 0.02, 0.0, "config 3 at B = 112: large enough for the EIGHTH first stage (mask 0x02)"),
+    (2, 200, 320, 1, 40000, 0.30, 0.2, "40 000 hypotheses = 79 groups: more than one pass may span (63 groups)"),
 ])
 def test_run_owning_filter_launch_branches(synth, pkg, gpu, B, H, W, K, hn, fg, outlier, what):
     """k_count_filter_runs (round 4: the staged pass's second launch -- runs of chunks, passes over hypothesis groups,
