@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     const int *__restrict__ tn_arr, int B, int K, int hn, int cap, float thresh, Bf16Consts fc, int target_items, int run_r, StageArgs sa)
 {
     __shared__ int run_end[kMaxBatchLds];           // inclusive prefix of the runs per image
-    __shared__ int s_R, s_runs;
+    __shared__ int s_R, s_runs, s_gpi;
     __shared__ bf16x8 sB[kBfMaxHt * 64];            // B operands of the staged survivors (16 KB)
     __shared__ float4 sP[4 * kBfPixPerWave];        // per pixel: (nhx, nhy, c'x, c'y); nhx = NaN: can never vote  (8 KB)
     __shared__ int sCnt[kRunSlots];
@@ -91,9 +91,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         // forced run lengths): B = 64 -> R = 3 wins (1728 items; 2: +4 %, 5: +2 %, 9: +5 %), B = 32 -> 2 or 3,
         // B = 128 -> 5, B = 16 -> 1, config 5 at B = 16 -> 9; the rule "at most ONE item per block" (longer runs: every item starts
         // at once, more elimination) lost 1-3 % at B = 16 ... 64.  run_r > 0 (tuning builds) forces the length.
+        // Hypothesis groups per item: all of them when few hypotheses survive (ransac_voting_layer_v3: 15 % of 2048 are one pass), ONE
+        // when most do (the estimate, sub_tenth: ~3/4 of 4096 survive the first stage -- an item that walked six passes over its
+        // run was as long as six v3 items, and 1728 of those on 1280 block slots left a third of the chip idle: the staged estimate
+        // measured 4-11 % SLOWER than the full pass until its items were cut by groups).  The work units that the run length
+        // balances are then chunks x group ranges.
+        const int gpi = sa.sub_tenth ? 1 : nhg;
+        const int ngr = (nhg + gpi - 1) / gpi;
         int R = run_r;
         if (R <= 0) {
-            const long long r = target_items > 0 ? ((long long)total * K) / target_items : 1;
+            const long long r = target_items > 0 ? ((long long)total * K * ngr) / target_items : 1;
             R = (int)(r < 1 ? 1 : r);
             // runs of equal length: nruns = ceil(n / R) runs of n / nruns chunks -- for the typical image of the batch, take
             // the length those runs really have (9 chunks, R = 4 -> 3 runs of 3)
@@ -108,17 +115,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             if (b < B) run_end[b] = inc;
             carry = __builtin_amdgcn_readlane(inc, 63);
         }
-        if (lane == 0) { s_R = R; s_runs = carry; }
+        if (lane == 0) { s_R = R; s_runs = carry; s_gpi = gpi; }
     }
     __syncthreads();
     const int R = __builtin_amdgcn_readfirstlane(s_R);
-    const int total = __builtin_amdgcn_readfirstlane(s_runs) * K;
+    const int gpi = __builtin_amdgcn_readfirstlane(s_gpi), ngr = (nhg + gpi - 1) / gpi;   // groups per item, group ranges per keypoint
+    const int per_run = K * ngr;
+    const int total = __builtin_amdgcn_readfirstlane(s_runs) * per_run;
     const int col = lane & 31, kslice = lane >> 5;
     const int ebase = kslice * 4;                                // this lane's pixels of a tile: ebase + e%4 + 8*(e/4)
     const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     for (int item = blockIdx.x; item < total; item += gridDim.x) {
-        const int grun = item / K, vi = item - grun * K;
+        const int grun = item / per_run, rem_i = item - grun * per_run;
+        const int vi = ngr == 1 ? rem_i : rem_i / ngr, gr = rem_i - vi * ngr;
+        const int g_begin = gr * gpi, g_end = min(nhg, g_begin + gpi);
         int r_img;
         const int b = locate_item(run_end, B, grun, &r_img);     // image, and the run's index within it
         const int bk = b * K + vi;
@@ -143,12 +154,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             lstar = stage_bound(__builtin_amdgcn_readfirstlane(full), tn, sa.sub_tenth);
         }
 
-        for (int g = 0; g < nhg;) {
+        for (int g = g_begin; g < g_end;) {
             // ================= a pass: the survivors of groups gp0 .. g-1 (as many consecutive groups as fit the slots)
             const int gp0 = g;
             int ns = 0;
             __syncthreads();                                     // the previous pass / item is done with sCnt, sPrev, s_keep
-            for (; g < nhg && g - gp0 < 63; ++g) {             // (a slot's hypothesis index relative to the pass: 15 bits)
+            for (; g < g_end && g - gp0 < 63; ++g) {             // (a slot's hypothesis index relative to the pass: 15 bits)
                 bool keep[2];
                 int slack[2];
                 unsigned long long m[2];
@@ -379,6 +390,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 //      misses among the R remaining pixels) <= partial(h) + R - miss_seen(h): h is dropped as soon as that is
                 //      below L*.  miss[] only grows and every (pixel, h) is evaluated by exactly one block, so ANY value read
                 //      -- however stale -- is a valid lower bound of the misses: no ordering between blocks is needed.
+                // (running this step only every third chunk when the slots are full -- the estimate's passes: 512 returning atomics per
+                //  chunk -- was measured: worse, the hypotheses it would have dropped are multiplied for two more chunks)
                 {
                     const bool last = j + 1 >= j1;
                     bool keep[2];

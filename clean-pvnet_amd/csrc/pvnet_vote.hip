@@ -539,11 +539,13 @@ CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
 // whose ratio lies within 0.1 of the best (P:262-264), so its count pass may drop what provably falls below that window
 // (stage_bound, count_bf16.hpp) when nobody asked for the counts themselves.  Covariances and PnP weights are bit-identical to the
 // full pass (tests/test_gpu_staged.py), a third of the hypothesis-tile work goes away (42 % of the hypotheses carry weight, 74 %
-// survive a quarter of the pixels, the pooled misses drop the rest as they go) -- and the call is SLOWER: 4096 hypotheses at
-// 480x640, K = 9: 1.60 vs 1.43 ms at B = 64 (1.49 with a quarter as first stage), 0.293 vs 0.221 at B = 8, 0.197 vs 0.053 at
-// B = 1; config 5's 2048 at B = 16: 1.72 vs 1.58 (tools/estimate_ab.py, profiles/r04_experiments.txt).  The full kernel builds a
-// chunk's pixel operands once for all eight hypothesis groups and runs VALU-saturated (busy 1.00); the second launch walks its
-// survivors in passes of 512 and rebuilds them per pass.  PVV_COUNT_STAGED still forces it (the tests' cross-check).
+// survive a quarter of the pixels, the pooled misses drop the rest as they go) -- and the call does not get reliably faster.  4096
+// hypotheses at 480x640, K = 9, staged vs full (tools/estimate_ab.py, profiles/r04_experiments.txt): with items that walked all
+// eight hypothesis groups in passes 1.60 vs 1.43 ms at B = 64, 0.293 vs 0.221 at B = 8, 0.197 vs 0.053 at B = 1; with items cut by
+// groups (count_filter_runs.hpp) 1.437 vs 1.402 at B = 64, **0.682 vs 0.741 at B = 32, 0.382 vs 0.421 at B = 16**, 0.225 vs 0.219 at
+// B = 8, 0.074 vs 0.054 at B = 1; config 5's 2048 at B = 16: 1.54 vs 1.54.  The full kernel builds a chunk's pixel operands once
+// for all eight groups and runs VALU-saturated (busy 1.00); the second launch pays its per-chunk prologue per 512 survivors and
+// runs at ~0.55.  PVV_COUNT_STAGED still forces it (the tests' cross-check of the bound).
 bool est_stage_auto(const pvv_problem *) { return false; }
 
 // kind: 0 = the pass must deliver every count (the estimate when its counts are an output, the fused un_pnp pass);
