@@ -1,4 +1,4 @@
-// count_filter_runs.hpp -- stage 3, second launch of the staged count (ransac_voting_layer_v3 only), round 4:
+// count_filter_runs.hpp -- stage 3, second launch of the staged count (ransac_voting_layer_v3; the estimate when forced), round 4:
 // work items that OWN A RUN of an (image, keypoint)'s remaining chunks, with progressive elimination inside the run.
 // Part of the single translation unit pvnet_vote.hip (included inside its anonymous namespace, after count_bf16.hpp);
 // see that file for the numerical contract and the matrix-core prefilter, count_prune.hpp for the bound L*.
@@ -28,9 +28,10 @@
 //     32-hypothesis tile; what a dropped hypothesis counted in this run is discarded (its counter keeps a partial count).
 //   * R is chosen on the device so that the launch still has about `target_items` items (one generation of blocks):
 //     runs of 3 at config 3 / B = 64 (9 remaining chunks per image), of 9 at config 5 / B = 16 (44 of them).
-// Hypothesis counts above 512 are handled in PASSES: the survivors of as many consecutive 512-hypothesis groups as fit the
-// 512 staging slots are collected, the run is walked for them, and the next pass takes the next groups (with the 15 %
-// survival of a clean field 2048 hypotheses are one pass).
+// Hypothesis counts above 512 are handled in PASSES: the survivors of as many consecutive 512-hypothesis groups (at most 63) as
+// fit the 512 staging slots are collected, the run is walked for them, and the next pass takes the next groups (with the 15 %
+// survival of a clean field 2048 hypotheses are one pass).  For the estimate (StageArgs.sub_tenth: three quarters survive) an
+// item takes ONE group, and the item count that R balances is chunks x groups.
 // sCnt[slot] = (hypothesis index relative to the pass's first group) << 16 | inliers counted in this run (< 2^16: a run is
 // at most 64 chunks); sPrev[slot] = that count at the slot's last elimination step (the next step publishes the difference).
 // ---------------------------------------------------------------------------------------------
