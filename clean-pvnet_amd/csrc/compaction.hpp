@@ -680,10 +680,58 @@ __global__ __launch_bounds__(kBlock) void k_compact_hyp(MaskArgs a, VertexArgs v
     if (sub) {
         const float prob = (float)a.max_num / (float)tot.fg;
         int cnt = 0;
-        for (int i = 0; i < t; ++i) {
-            const int ni = (int)(tiles[b * a.T + i] & kTileNzMask);                 // block-uniform
-            for (int e = threadIdx.x; e < ni; e += kBlock)
-                cnt += list_draw(a, b, i, e, img_lists, img_draws) < prob ? 1 : 0;
+        if (img_draws || a.T > kBlock) {                                            // (never with the host's rule: fused = on-demand draws, <= 160 tiles)
+            for (int i = 0; i < t; ++i) {
+                const int ni = (int)(tiles[b * a.T + i] & kTileNzMask);             // block-uniform
+                for (int e = threadIdx.x; e < ni; e += kBlock)
+                    cnt += list_draw(a, b, i, e, img_lists, img_draws) < prob ? 1 : 0;
+            }
+        } else {
+            // The lists of the tiles before t as ONE sequence of 8-entry groups (16 bytes), dealt round-robin to the threads, four
+            // loads per thread in flight.  (Until round 4 this was a loop over the tiles with a block-uniform load of the tile's
+            // count and then its entries -- two dependent round trips per tile, 47.6 us for the LAST tile of a dense 480x640 image,
+            // tn = 30 000: profiles/r04_configs.json cfg2_dense_tn30000_B1.)  s_prefix (the dynamic LDS of the hypothesis blocks):
+            // inclusive prefix of the tiles' group counts; the tile of a thread's next group is found by walking on from its last.
+            const int ti = threadIdx.x;
+            const int nzi = ti < t ? (int)(tiles[b * a.T + ti] & kTileNzMask) : 0;
+            const int inc = wave_incl_scan((nzi + 7) >> 3);
+            __syncthreads();
+            if (lane == 63) red[wave] = inc;
+            __syncthreads();
+            int goff = 0;
+            for (int w2 = 0; w2 < wave; ++w2) goff += red[w2];
+            if (ti < a.T) s_prefix[ti] = inc + goff;
+            list[ti] = (unsigned short)nzi;                                         // (list[] is free until filter_tile_list: the tiles' counts)
+            __syncthreads();
+            const int groups = t ? s_prefix[t - 1] : 0;
+            constexpr int kAhead = 4;
+            int tile = 0;
+            for (int g0 = threadIdx.x; g0 < groups; g0 += kAhead * kBlock) {
+                uint4 ent[kAhead];
+                int left[kAhead], pix0[kAhead];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    const int g = g0 + u * kBlock;
+                    left[u] = 0;
+                    if (g < groups) {
+                        while (s_prefix[tile] <= g) ++tile;
+                        const int e0 = (g - (tile ? s_prefix[tile - 1] : 0)) * 8;
+                        ent[u] = *(const uint4 *)(img_lists + (size_t)tile * kTile + e0);
+                        left[u] = (int)list[tile] - e0;                     // valid entries of the group (>= 1; more than 8: all)
+                        pix0[u] = tile * kTile;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    const uint32_t wds[4] = {ent[u].x, ent[u].y, ent[u].z, ent[u].w};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (q < left[u]) {
+                            const int off = (int)((wds[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+                            cnt += selection_draw(a, b, pix0[u] + off) < prob ? 1 : 0;
+                        }
+                }
+            }
         }
         before = block_sum(cnt, red);
         __syncthreads();

@@ -345,6 +345,50 @@ def test_v3_subsample_fused_into_compaction_at_480x640(oracle, synth, pkg, gpu):
     _check_v3(oracle, out, win, tnn, mask, vertex, idxs, hn, 0.99, selection=selection, max_num=30000)
 
 
+def _counter_rng_draws(seed, image, n_pixels):
+    """numpy restatement of the library's counter RNG for the subsample draws (vote_common.hpp rng_u32, stream 0, key
+    (image, pixel)): splitmix64 finaliser, top 24 bits -> U[0,1)."""
+    def mix64(z):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        k = mix64(np.array([seed], np.uint64) + np.uint64(0x9E3779B97F4A7C15) * np.uint64(1))
+        x = (np.uint64(image) << np.uint64(32)) | np.arange(n_pixels, dtype=np.uint64)
+        u = (mix64(k ^ x) >> np.uint64(32)).astype(np.uint32)
+    return ((u >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24))
+
+
+def test_fused_subsample_with_the_device_rng_equals_injected_draws_at_480x640(oracle, synth, pkg, gpu):
+    """The path a dense image takes in production: 480x640 (150 tiles), ~12 % foreground (37 k pixels > max_num = 30000), no
+    injected tensors -- k_compact_hyp subsamples itself, every tile block re-evaluating the counter RNG for the listed pixels of
+    the tiles before it (round 4: as one sequence of 16-byte list groups).  The same call with the SAME draws injected as a
+    selection tensor (numpy restatement of the generator) must give identical tn, winners and means; tn equals the count of
+    draws below max_num / foreground_num; the second image (2 % foreground) is not subsampled; and a call that takes the other
+    route (injected index pairs -> k_tile_subsample) keeps the same pixels."""
+    from clean_pvnet_amd import ransac_voting as ext
+    d0 = synth.make_batch(B=1, H=480, W=640, K=3, fg=0.12, sigma=0.05, seed=91)
+    d1 = synth.make_batch(B=1, H=480, W=640, K=3, fg=0.02, sigma=0.05, seed=92)
+    mask, vertex = torch.cat([d0["mask"], d1["mask"]]), torch.cat([d0["vertex"], d1["vertex"]])
+    seed, hn = 424242, 128
+    sel = torch.from_numpy(np.stack([_counter_rng_draws(seed, b, 480 * 640).reshape(480, 640) for b in range(2)]))
+    fg = mask.sum((1, 2)).float()
+    assert float(fg[0]) > 30000 > float(fg[1])
+    prob = (torch.tensor(30000.0) / fg).view(-1, 1, 1)
+    kept = (mask != 0) & ((fg <= 30000).view(-1, 1, 1) | (sel < prob))
+    tn_want = [int(x) for x in kept.sum((1, 2))]
+    m, v = mask.to(gpu), vertex.to(gpu)
+    out, win, tn, _ws = ext.ransac_voting_v3(m, v, hn, 0.99, 5, 30000, None, None, seed, ext.SINGULAR_REFERENCE)
+    out_i, win_i, tn_i, _ws = ext.ransac_voting_v3(m, v, hn, 0.99, 5, 30000, None, sel.to(gpu), seed, ext.SINGULAR_REFERENCE)
+    assert _np(tn).tolist() == tn_want == _np(tn_i).tolist()
+    assert torch.equal(out, out_i) and torch.equal(win, win_i)
+    assert np.abs(_np(out) - np.concatenate([_np(d0["kpt_2d"]), _np(d1["kpt_2d"])])).max() < 10.0     # (128 hypotheses, sigma = 0.05: a sanity bound)
+    idxs = synth.make_idxs(tn_want, hn, 3, seed=9)
+    out_t, win_t, tn_t, _ws = ext.ransac_voting_v3(m, v, hn, 0.99, 5, 30000, idxs.to(gpu), None, seed, ext.SINGULAR_REFERENCE)
+    assert _np(tn_t).tolist() == tn_want
+    _check_v3(oracle, out_t, win_t, tn_t, mask, vertex, idxs, hn, 0.99, selection=sel, max_num=30000)
+
+
 # --------------------------------------------------------------------------------------------------
 # estimate_voting_distribution_with_mean
 # --------------------------------------------------------------------------------------------------

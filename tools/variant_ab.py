@@ -51,12 +51,15 @@ def main():
                     help="count: re-launches of the inlier-count kernel; v3: whole pvv_ransac_voting_v3 calls; decode: whole "
                          "pvv_decode_keypoint_v3 calls on seg logits + the planar vertex view (one [B,2+2K,H,W] tensor, resnet18.py:93)")
     ap.add_argument("--outlier", type=float, default=None, help="fraction of foreground pixels with a random direction")
+    ap.add_argument("--fg", type=float, default=None, help="foreground fraction (0.0985 at 480x640: the dense stress, tn ~ 30000)")
     ap.add_argument("--rotate", type=int, default=1, help="v3 mode: cycle over this many distinct device-resident batches (cold caches)")
     a = ap.parse_args()
     synth = _synth()
     cfg = dict(synth.CONFIGS[a.config])
     if a.outlier is not None:
         cfg["outlier"] = a.outlier
+    if a.fg is not None:
+        cfg["fg"] = a.fg
     B = a.batch or cfg["B"]
     hn = a.hn or cfg["hn"]
     dev = torch.device("cuda:0")
