@@ -178,16 +178,25 @@ bool use_bf16_count(const pvv_problem *p)
 // DEVICE refines it per image: images of fewer than 8 chunks (tn <= 3584) are counted completely by the first launch, and
 // when no image of the batch is staged the two later launches leave at their first instruction (config 4's sparse masks
 // at B = 32: the call then costs ~5 us more than the full pass, the price of not knowing tn on the host).
+// Round 4, later: that proxy is calibrated on LINEMOD-like frames (2 % foreground).  T-LESS votes on detector crops (128x128 / 256x256,
+// a third of the pixels foreground, B = #detections): 16 crops of 256x256 are 1.7e9 evaluations -- the benchmark's 64
+// frames are 1.8e9 -- behind a proxy of 4.8e9, and staging them is worth +34 % per call (profiles/r04_experiments.txt (17)).  So the
+// decision now uses the evaluations themselves whenever the stage hint knows the last call's tn (work_equivalent: K*hn*sum(tn) scaled
+// to the proxy's units, x 50 = 1 / 0.02), the proxy only before any call has reported; and may_stage -- what reserves the leader words
+// and lets a call leave its hint -- asks whether the problem COULD reach the bound: B*K*hn*min(H*W, cap) evaluations at most.
 constexpr double kStageMinWork = 2e10;
+constexpr double kStageProxyFg = 0.02;      // tn / (H*W) of the frames the proxy and the threshold table were measured on
 bool may_stage(const pvv_problem *p)
 {
     if (!use_bf16_count(p) || p->count_kernel == PVV_COUNT_FULL) return false;
     if (p->count_kernel == PVV_COUNT_STAGED) return true;
     // cap bounds tn: with fewer than 8 chunks of rows reserved per image nothing can ever be staged (the reference's default
     // call, max_num = 100: 244 rows)
+    const double rows = std::min((double)p->H * p->W, (double)p->cap);
     return p->hn >= 128 && p->cap >= kStageMinChunks * 4 * kBfPixPerWave &&
-           (double)p->B * p->K * p->hn * p->H * p->W >= kStageMinWork;
+           (double)p->B * p->K * p->hn * rows >= kStageMinWork * kStageProxyFg;
 }
+double stage_proxy_work(const pvv_problem *p) { return (double)p->B * p->K * p->hn * p->H * p->W; }
 
 // ---------------------------------------------------------------------------------------------
 // The stage hint.  Whether staged counting pays depends on how clean the vector field is -- on the winners' inlier ratio
@@ -261,9 +270,10 @@ float *stage_hint_claim(const pvv_problem *p, hipStream_t st)
 }
 
 // mean winner ratio of the images the last calls OF THIS SHAPE reported (< 0: no data) and the largest tn among them
-float stage_hint_mean(const pvv_problem *p, hipStream_t st, float *max_tn = nullptr)
+float stage_hint_mean(const pvv_problem *p, hipStream_t st, float *max_tn = nullptr, double *sum_tn = nullptr)
 {
     if (max_tn) *max_tn = -1.f;
+    if (sum_tn) *sum_tn = -1.0;
     std::lock_guard<std::mutex> lock(g_hint_mu);
     StageHint *g = stage_hint_locked(st, false);
     if (!g || g->n <= 0) return -1.f;
@@ -271,7 +281,7 @@ float stage_hint_mean(const pvv_problem *p, hipStream_t st, float *max_tn = null
         const int shape[5] = {p->B, p->H, p->W, p->K, p->hn};
         if (memcmp(g->shape, shape, sizeof(shape)) != 0) return -1.f;
     }
-    double sum = 0;
+    double sum = 0, stn = 0;
     int cnt = 0;
     float mt = 0.f;
     const volatile float *r = g->ratio;
@@ -280,8 +290,10 @@ float stage_hint_mean(const pvv_problem *p, hipStream_t st, float *max_tn = null
         if (v < -1.5f) return -1.f;                                       // an image of the last call has not reported yet
         if (v >= 0.f) { sum += v; ++cnt; }
         mt = std::max(mt, (float)r[kMaxBatchLds + i]);
+        stn += std::max(0.f, (float)r[kMaxBatchLds + i]);
     }
     if (max_tn) *max_tn = mt;
+    if (sum_tn && cnt) *sum_tn = stn;
     return cnt ? (float)(sum / cnt) : -1.f;
 }
 
@@ -312,10 +324,10 @@ long long stage_hint_rest_chunks(const pvv_problem *p, hipStream_t st, uint32_t 
 // for 128 (round 3's kernel: 0.976 / 0.941 / 0.906 at B = 16 / 32 / 64); 540x720, K = 17, 2048 hypotheses at B = 16 gains at
 // every ratio measured (+10 % at 0.71).  Interpolated in x = log2(B*K*hn*H*W / 2.26e10); more hypotheses per keypoint
 // lower it further.
-float stage_hint_threshold(const pvv_problem *p)
+float stage_hint_threshold(const pvv_problem *p, double work)
 {
     static const double xs[6] = {0.0, 0.585, 1.0, 1.585, 2.0, 3.0}, ys[6] = {0.990, 0.966, 0.957, 0.910, 0.765, 0.50};
-    const double x = std::log2((double)p->B * p->K * p->hn * p->H * p->W / 2.26e10);
+    const double x = std::log2(std::max(work, 1.0) / 2.26e10);
     double thr;
     if (x <= xs[0]) thr = ys[0] + (ys[1] - ys[0]) / (xs[1] - xs[0]) * (x - xs[0]);
     else if (x >= xs[5]) thr = ys[5];
@@ -328,15 +340,29 @@ float stage_hint_threshold(const pvv_problem *p)
     return (float)std::min(0.995, std::max(0.5, thr));
 }
 
+// The evaluations of a full pass in the proxy's units (B*K*hn*H*W of a frame with 2 % foreground): K*hn*sum(tn) / 0.02 when the last
+// call of this shape has reported its images' tn, the proxy itself otherwise.  *mean / *max_tn: the hint's (see stage_hint_mean).
+double stage_work(const pvv_problem *p, hipStream_t st, float *mean = nullptr, float *max_tn = nullptr)
+{
+    double sum_tn = -1.0;
+    float mt = -1.f;
+    const float m = stage_hint_mean(p, st, &mt, &sum_tn);
+    if (mean) *mean = m;
+    if (max_tn) *max_tn = mt;
+    if (m < 0.f || sum_tn < 0.0) return stage_proxy_work(p);
+    return (double)p->K * p->hn * sum_tn / kStageProxyFg;
+}
+
 bool stage_hint_allows(const pvv_problem *p, hipStream_t st)
 {
     if (p->count_kernel != PVV_COUNT_AUTO) return true;
-    float max_tn = -1.f;
-    const float m = stage_hint_mean(p, st, &max_tn);
-    if (m < 0.f) return true;
+    float max_tn = -1.f, m = -1.f;
+    const double work = stage_work(p, st, &m, &max_tn);
+    if (work < kStageMinWork) return false;                               // too few evaluations for the two extra launches to pay
+    if (m < 0.f) return true;                                             // no data yet: by the proxy alone
     // (images of fewer than kStageMinChunks chunks are counted completely by the first launch: when the last calls held
     // no larger one -- config 4's sparse masks -- the two later launches would only be launched to leave again)
-    return m >= stage_hint_threshold(p) && max_tn > (float)((kStageMinChunks - 1) * 4 * kBfPixPerWave);
+    return m >= stage_hint_threshold(p, work) && max_tn > (float)((kStageMinChunks - 1) * 4 * kBfPixPerWave);
 }
 
 Bf16Consts bf16_consts(float thresh)
@@ -514,7 +540,7 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     sl.p = p; sl.ws = ws; sl.L = &L; sl.st = st; sl.fc = fc; sl.dbg = dbg;
     sl.per_cu_first = per_cu_first; sl.per_cu_filter = per_cu_filter; sl.target_first = target_first; sl.target_filter = target_filter;
     sl.sub_tenth = staged == 2 ? 1 : 0;
-    const bool eighth = tuning_int("PVV_STAGE_EIGHTH", (double)p->B * p->K * p->hn * p->H * p->W >= 2.26e10 * 4.757 ? 1 : 0) != 0;
+    const bool eighth = tuning_int("PVV_STAGE_EIGHTH", (p->count_kernel == PVV_COUNT_AUTO ? stage_work(p, st) : stage_proxy_work(p)) >= 2.26e10 * 4.757 ? 1 : 0) != 0;
     return eighth ? launch_staged<kStageFirstEighth>(sl) : launch_staged<kStageFirst>(sl);
 }
 
@@ -819,9 +845,14 @@ PVV_EXPORT const char *pvv_last_error(void) { return g_err; }
 
 PVV_EXPORT int pvv_stage_hint_query(float *mean_ratio, float *threshold, const pvv_problem *p, void *stream)
 {
-    const float m = stage_hint_mean(p, (hipStream_t)stream);
+    float m = stage_hint_mean(p, (hipStream_t)stream);
+    if (threshold) *threshold = -1.f;
+    if (p) {
+        const double work = stage_work(p, (hipStream_t)stream, &m);
+        // (a problem whose evaluations stay below the bound is never staged by AUTO: reported as a threshold no ratio reaches)
+        if (threshold) *threshold = work >= kStageMinWork ? stage_hint_threshold(p, work) : 2.f;
+    }
     if (mean_ratio) *mean_ratio = m;
-    if (threshold) *threshold = p ? stage_hint_threshold(p) : -1.f;
     return m >= 0.f ? 1 : 0;
 }
 

@@ -277,9 +277,13 @@ int pvv_stream_read_probe(const void *d_buf, size_t bytes, uint32_t *d_sink, voi
  * the exact winner counts.  The library therefore keeps, per device, the mean winner ratio (winner count / tn) of every
  * image of the last completed v3 calls in a small pinned array the GPU writes, and PVV_COUNT_AUTO stages a call only if
  * that mean reaches a threshold that depends on the problem's size (pvnet_vote.hip, stage_hint_threshold; DESIGN.md
- * 4.6).  The hint lags by the calls in flight and only selects between two exact paths; with no data yet the call is
- * staged; PVV_COUNT_STAGED / PVV_COUNT_FULL ignore it.  This query is for tests, benches and the curious: returns 1 and
- * the mean when data is there (0 and -1 otherwise), and the threshold of `p` (p may be NULL: -1). */
+ * 4.6-4.7).  The same array carries every image's tn, so the size that decides is the call's real work -- K * hn * sum(tn)
+ * evaluations as the last call of this shape reported them (dense detector crops stage at a batch size where sparse full
+ * frames do not) -- and B*K*hn*H*W, a proxy calibrated on frames with 2 % foreground, only while no call has reported.  The
+ * hint lags by the calls in flight and only selects between two exact paths; with no data yet the proxy alone decides;
+ * PVV_COUNT_STAGED / PVV_COUNT_FULL ignore it.  This query is for tests, benches and the curious: returns 1 and
+ * the mean when data is there (0 and -1 otherwise), and the threshold of `p` (p may be NULL: -1; 2 = a problem with too
+ * little work to be staged at all). */
 int pvv_stage_hint_query(float *mean_ratio, float *threshold, const pvv_problem *p, void *stream);
 
 /* Bench / profiling aid: re-runs ONLY the inlier-count kernel of the last

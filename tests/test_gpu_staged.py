@@ -294,6 +294,33 @@ def test_stage_marks_and_stream_probe(synth, pkg, gpu):
         ext.rerun_count_kernel(d["mask"], d["vertex"], 512, 0.99, 5, 30000, ws, False, ext.COUNT_STAGED)
 
 
+def test_auto_stages_dense_crops_by_their_real_work(synth, pkg, gpu):
+    """T-LESS votes on detector crops (256x256, a third of the pixels foreground): 16 of them are as many evaluations
+    as 59 LINEMOD frames behind a B*K*hn*H*W of 4.8e9 -- below the 2e10 of the frame-calibrated proxy.  Once a call of the shape has
+    reported its images' tn, AUTO decides on K * hn * sum(tn): the first call runs the full pass (no data: proxy), the following ones
+    are staged; the same crops with 2 % foreground are not; results equal the full pass either way."""
+    from clean_pvnet_amd import ransac_voting as ext
+    hn = 512
+    for fg, want_staged in ((0.35, True), (0.02, False)):
+        d = synth.make_batch(B=16, H=256, W=256, K=9, fg=fg, sigma=0.05, seed=300 + int(fg * 100), device=gpu)
+        d2 = synth.make_batch(B=15, H=256, W=256, K=9, fg=fg, sigma=0.05, seed=400, device=gpu)      # another shape: resets the hint
+        ext.ransac_voting_v3(d2["mask"], d2["vertex"], hn, 0.99, 5, 30000, None, None, 5, ext.SINGULAR_REFERENCE, count_kernel=ext.COUNT_AUTO)
+
+        def v3(k):
+            return ext.ransac_voting_v3(d["mask"], d["vertex"], hn, 0.99, 5, 30000, None, None, 5, ext.SINGULAR_REFERENCE, count_kernel=k)
+
+        ms = ext.stage_ms_in_pipeline([d["mask"]], [d["vertex"]], hn, 0.99, 5, 30000, 5, 1, ext.COUNT_AUTO)
+        assert ms[0][5] < 0, ms                                       # first call of the shape: proxy 4.8e9 < 2e10, full pass
+        torch.cuda.synchronize()
+        valid, mean, thr = ext.stage_hint(d["mask"], d["vertex"], hn)
+        assert valid and mean > 0.98
+        assert (thr <= 0.995) == want_staged, thr                     # 2.0 = too little work
+        ms = ext.stage_ms_in_pipeline([d["mask"]], [d["vertex"]], hn, 0.99, 5, 30000, 5, 3, ext.COUNT_AUTO)
+        assert all((r[5] > 0) == want_staged for r in ms), ms
+        ref, got = v3(ext.COUNT_FULL), v3(ext.COUNT_AUTO)
+        assert all(torch.equal(a, b) for a, b in zip(got[:3], ref[:3]))
+
+
 def test_auto_follows_the_stage_hint(synth, pkg, gpu):
     """PVV_COUNT_AUTO stages a v3 call only if the winner ratios the last completed calls left in the per-device hint
     reach the problem's threshold (pvv_stage_hint_query): after calls on a clean field the next calls are staged, after

@@ -43,6 +43,11 @@ ROWS = [
     ("cfg3_B64_decode_unfused", "cfg3", 64, {"seg": True, "unfused": True}),  # torch.argmax + v3, as resnet18.py:69-71 runs it
     ("cfg2_B1_decode_fused", "cfg2", 1, {"seg": True}),
     ("cfg2_B1_decode_unfused", "cfg2", 1, {"seg": True, "unfused": True}),
+    # T-LESS runs the voting on DETECTOR CROPS, one per detection (lib/datasets/tless_test/pvnet.py:75-89, 128x128 and
+    # 256x256, B = #detections, K = 9): small images whose tiles are dense in foreground
+    ("tless_crop128_B8", "cfg3", 8, {"H": 128, "W": 128, "fg": 0.35}),
+    ("tless_crop256_B8", "cfg3", 8, {"H": 256, "W": 256, "fg": 0.35}),
+    ("tless_crop256_B16_decode_fused", "cfg3", 16, {"H": 256, "W": 256, "fg": 0.35, "seg": True}),
 ]
 
 
@@ -55,6 +60,7 @@ def make_case(name, dev):
     from lib.csrc.ransac_voting.ransac_voting_gpu import ransac_voting_layer_v3
     _n, cfgname, B, over = [r for r in ROWS if r[0] == name][0]
     cfg = dict(synth.CONFIGS[cfgname])
+    cfg.update({k: over[k] for k in ("H", "W") if k in over})
     H, W, K = cfg["H"], cfg["W"], cfg["K"]
     hn = over.get("hn", cfg["hn"])
     max_num = over.get("max_num", 30000)

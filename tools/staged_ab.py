@@ -36,6 +36,8 @@ def main():
                     help="override the configs' outlier fraction: pixels whose direction is random (a winner then explains "
                          "fewer pixels and the elimination bites later or not at all)")
     ap.add_argument("--sigma", type=float, default=None, help="override the configs' direction noise")
+    ap.add_argument("--size", default=None, help="HxW override (T-LESS detector crops: 128x128, 256x256)")
+    ap.add_argument("--fg", type=float, default=None, help="foreground fraction override")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -50,8 +52,13 @@ def main():
             gen["outlier"] = args.outlier
         if args.sigma is not None:
             gen["sigma"] = args.sigma
+        if args.size:
+            gen["H"], gen["W"] = (int(x) for x in args.size.split("x"))
+        if args.fg is not None:
+            gen["fg"] = args.fg
         batches = [synth.make_batch(B=B, **gen, first_index=1000 * r, device=dev) for r in range(args.rotate)]
-        row = {"case": case, "hn": hn, "K": K, "outlier": gen.get("outlier", 0.0), "sigma": gen.get("sigma")}
+        row = {"case": case, "hn": hn, "K": K, "outlier": gen.get("outlier", 0.0), "sigma": gen.get("sigma"), "H": gen["H"], "W": gen["W"],
+               "fg": gen.get("fg")}
         outs = {}
         for name, mode in (("full", ext.COUNT_FULL), ("staged", ext.COUNT_STAGED), ("auto", ext.COUNT_AUTO)):
             def call(i):
