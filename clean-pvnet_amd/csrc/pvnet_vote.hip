@@ -512,7 +512,15 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     // the kernel alive 2 us after the last working block at B = 1; 15 per CU lose 6 % at B = 16 and win 8 % at B = 24.
     // The host does not know tn: up to B = 8 it launches the one generation, beyond that 15 per CU (48 for >= 2048
     // hypotheses: long, uneven items) and the KERNEL falls back to one generation when it finds few items (count_bf16.hpp).
-    const int per_cu = per_cu_t > 0 ? per_cu_t : (p->B <= 8 ? 5 : (p->hn < 2048 ? 15 : 48));
+    // (Round 4: when the stage hint knows the tn of the last call of this shape, "few items" is decided on them instead of on B --
+    // eight dense 256x256 crops are 3240 (chunk, keypoint) pairs, as many as 34 LINEMOD frames: 15 per CU -3.4 % per call there.)
+    bool few = p->B <= 8;
+    if (p->count_kernel == PVV_COUNT_AUTO) {
+        double sum_tn = -1.0;
+        if (stage_hint_mean(p, st, nullptr, &sum_tn) >= 0.f && sum_tn >= 0.0)
+            few = sum_tn / (4 * kBfPixPerWave) * p->K * ((p->hn + 511) / 512) <= 2000.0;
+    }
+    const int per_cu = per_cu_t > 0 ? per_cu_t : (few ? 5 : (p->hn < 2048 ? 15 : 48));
     const float2 *coords = (const float2 *)(ws + L.coords), *dirs = (const float2 *)(ws + L.dirs);
     const float2 *hyps = (const float2 *)(ws + L.hyps);
     int *counts = (int *)(ws + L.counts);

@@ -52,6 +52,8 @@ def main():
                          "pvv_decode_keypoint_v3 calls on seg logits + the planar vertex view (one [B,2+2K,H,W] tensor, resnet18.py:93)")
     ap.add_argument("--outlier", type=float, default=None, help="fraction of foreground pixels with a random direction")
     ap.add_argument("--fg", type=float, default=None, help="foreground fraction (0.0985 at 480x640: the dense stress, tn ~ 30000)")
+    ap.add_argument("--size", default=None, help="HxW override (T-LESS detector crops: 128x128, 256x256)")
+    ap.add_argument("--count-kernel", type=int, default=0, help="pvv_problem.count_kernel (0 AUTO, 2 FULL, 3 STAGED)")
     ap.add_argument("--rotate", type=int, default=1, help="v3 mode: cycle over this many distinct device-resident batches (cold caches)")
     a = ap.parse_args()
     synth = _synth()
@@ -60,6 +62,8 @@ def main():
         cfg["outlier"] = a.outlier
     if a.fg is not None:
         cfg["fg"] = a.fg
+    if a.size:
+        cfg["H"], cfg["W"] = (int(x) for x in a.size.split("x"))
     B = a.batch or cfg["B"]
     hn = a.hn or cfg["hn"]
     dev = torch.device("cuda:0")
@@ -106,6 +110,7 @@ def main():
         p.mask_stride[:] = mask.stride()
         p.vertex_stride[:] = vertex.stride()
         p.seed = 12345
+        p.count_kernel = a.count_kernel
         if a.mode == "decode":
             p.seg_classes = 2
             p.seg_stride[:] = net[0][1].stride()
