@@ -232,7 +232,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         int htpi = min(nt, kBfMaxHt);
         int nhg = (nt + htpi - 1) / htpi;
         int gpi = nhg;                                              // groups per item
-        while (gpi > 1 && chunks * ((nhg + gpi - 1) / gpi) < target_items) gpi = (gpi + 1) >> 1;
+        // Long items (several 512-hypothesis groups behind one pixel-operand build) are split until there are THREE generations'
+        // worth of them when the grid has that many blocks (B > 8: 15 or 48 per CU) -- 1296 eight-group items on 1280 block slots
+        // (the 4096-hypothesis estimate at B = 12) leave 16 items a second round to themselves.  One-process A/B, count kernel,
+        // 480x640, K = 9 (profiles/r04_experiments.txt (19)): 4096 hypotheses -19 % at B = 12, -10 % at 16, -7 % at 24, -4 % at 32,
+        // +-0 from 48 on; 2048 hypotheses -7.5 % at B = 16; config 5's staged first launch -3 % at B = 16.  Not below B = 9 (the
+        // one-generation grid walks its items round-robin: twice as many half-length items cost +9 % on config 5 at B = 2, and the
+        // estimate at B = 8) and not for two groups (1024 hypotheses at B = 16: +1.6 %).
+#ifndef PVV_GPI_FACTOR
+#define PVV_GPI_FACTOR 3
+#endif
+        const long long gpi_target = (B > 8 && nhg >= 4) ? (long long)PVV_GPI_FACTOR * target_items : (long long)target_items;
+        while (gpi > 1 && chunks * ((nhg + gpi - 1) / gpi) < gpi_target) gpi = (gpi + 1) >> 1;
         // groups below 4 tiles only for very small problems (< 128 (chunk, keypoint) pairs: every item they add is another
         // CU put to work); otherwise the prologue of an item is worth more than the 16 matrix-core tiles of a 2-tile group
         const int htpi_min = chunks < 128 ? 2 : 4;

@@ -481,7 +481,9 @@ int launch_staged(const StagedLaunch &a)
     // With runs of ONE chunk the new items only add their elimination step to round 3's (+2 % per call at config 3, B = 16 / 24):
     // when the images the last call of this shape reported (the stage hint: AUTO only) predict that, round 3's kernel runs.
     const long long rest = p->count_kernel == PVV_COUNT_AUTO ? stage_hint_rest_chunks(p, st, stage_rest_of(FIRST)) : -1;
-    const bool runs = rest < 0 || rest * p->K >= 2ll * a.target_filter;
+    // (Only up to 512 hypotheses: with several hypothesis groups a run-owning item walks the survivors of all of them in ONE pass,
+    // round 3's items one group each -- config 5 at B = 2, runs of one chunk: round 3's kernel +2.3 % per call.)
+    const bool runs = rest < 0 || rest * p->K >= 2ll * a.target_filter || p->hn > 512;
     if (tuning_int("PVV_FILTER_OLD", runs ? 0 : 1) == 0) {
         hipLaunchKernelGGL(k_count_filter_runs<FIRST>, dim3(tuning_int("PVV_GRID_PER_CU_FILTER", 5) * num_cus()), dim3(kBlock), 0, st, coords, dirs,
                            hyps, counts, tn, p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, a.target_filter, tuning_int("PVV_RUN_R", 0), sa);
@@ -520,7 +522,8 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
         if (stage_hint_mean(p, st, nullptr, &sum_tn) >= 0.f && sum_tn >= 0.0)
             few = sum_tn / (4 * kBfPixPerWave) * p->K * ((p->hn + 511) / 512) <= 2000.0;
     }
-    const int per_cu = per_cu_t > 0 ? per_cu_t : (few ? 5 : (p->hn < 2048 ? 15 : 48));
+    // (not few at B <= 8 -- only the hint can say so --: 15 per CU whatever hn; config 5 at B = 2, staged: 48 per CU +2 %)
+    const int per_cu = per_cu_t > 0 ? per_cu_t : (few ? 5 : ((p->hn < 2048 || p->B <= 8) ? 15 : 48));
     const float2 *coords = (const float2 *)(ws + L.coords), *dirs = (const float2 *)(ws + L.dirs);
     const float2 *hyps = (const float2 *)(ws + L.hyps);
     int *counts = (int *)(ws + L.counts);
