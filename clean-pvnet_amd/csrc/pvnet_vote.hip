@@ -583,6 +583,9 @@ CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
 // B = 8, 0.074 vs 0.054 at B = 1; config 5's 2048 at B = 16: 1.54 vs 1.54.  The full kernel builds a chunk's pixel operands once
 // for all eight groups and runs VALU-saturated (busy 1.00); the second launch pays its per-chunk prologue per 512 survivors and
 // runs at ~0.55.  PVV_COUNT_STAGED still forces it (the tests' cross-check of the bound).
+// (The lead at B = 16 ... 32 was the full pass's item quantisation, not the elimination: with long items split to three generations'
+// worth -- count_bf16.hpp -- the full estimate takes 0.376 ms at B = 16 and 0.707 at B = 32, and the staged one leads nowhere but
+// B = 32, by 4 %.)
 bool est_stage_auto(const pvv_problem *) { return false; }
 
 // kind: 0 = the pass must deliver every count (the estimate when its counts are an output, the fused un_pnp pass);
