@@ -35,6 +35,9 @@ table = '\n'.join([
     row('cfg3_B64_decode_fused', 'same, fused decode: seg logits + planar vertex → mask + keypoints (`pvv_decode_keypoint_v3`)'),
     row('cfg3_B64_decode_unfused', 'same, `torch.argmax` + v3 (what resnet18.py:69-71 runs)'),
     row('cfg2_B1_decode_fused', 'fused decode, B=1'), row('cfg2_B1_decode_unfused', '`torch.argmax` + v3, B=1'),
+    row('tless_crop128_B8', '**T-LESS-like detector crops** (SURVEY §8(d)): 128×128, 35 % foreground (tn ≈ 5.7 k), K=9, 512 hyp, B=8'),
+    row('tless_crop256_B8', 'same, 256×256 (tn ≈ 22.8 k), B=8 — staged by AUTO on the hint\'s tn (§4.7)'),
+    row('tless_crop256_B16_decode_fused', 'same, 256×256, B=16, fused decode (seg logits + planar vertex)'),
 ])
 bd = json.load(open('profiles/%s_bench_default.json' % T))
 ex = json.load(open('profiles/%s_bench_extras.json' % T))['extra']
