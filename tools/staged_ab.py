@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--sigma", type=float, default=None, help="override the configs' direction noise")
     ap.add_argument("--size", default=None, help="HxW override (T-LESS detector crops: 128x128, 256x256)")
     ap.add_argument("--fg", type=float, default=None, help="foreground fraction override")
+    ap.add_argument("--hn", type=int, default=None, help="hypotheses per keypoint override")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -46,7 +47,7 @@ def main():
         cfgname, B = case.split(":")
         B = int(B)
         cfg = dict(synth.CONFIGS[cfgname])
-        hn, K = cfg["hn"], cfg["K"]
+        hn, K = args.hn or cfg["hn"], cfg["K"]
         gen = {k: v for k, v in cfg.items() if k not in ("B", "hn")}
         if args.outlier is not None:
             gen["outlier"] = args.outlier
