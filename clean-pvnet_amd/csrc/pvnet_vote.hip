@@ -208,14 +208,16 @@ double stage_proxy_work(const pvv_problem *p) { return (double)p->B * p->K * p->
 // k_finalize_v3 leaves each image's mean winner ratio in a small host-visible array (one per device, pinned, written by
 // the GPU with plain stores), and AUTO stages a call only if the ratios the LAST completed calls left there reach a
 // threshold that depends on the problem's size.  The hint lags by the calls still in flight and mixes calls when several
-// streams interleave (a hint left by another problem SHAPE is ignored); it only ever selects between two exact paths.  No data yet (first call, or first
+// streams interleave (a hint left by another problem SHAPE -- H, W, K, hn; the batch size may vary -- is ignored); it only ever selects between two exact paths.  No data yet (first call, or first
 // call under stream capture, where no memory can be pinned): stage.  PVV_COUNT_STAGED / PVV_COUNT_FULL ignore it.
 // ---------------------------------------------------------------------------------------------
 struct StageHint {
     float *ratio = nullptr;   // 2 x kMaxBatchLds floats, hipHostMalloc: [b] winner ratio (< -1.5 = never written, -1 = skipped
                               // image), [kMaxBatchLds + b] the image's tn
     int n = 0;                // images of the last call that was given the buffer
-    int shape[5] = {0, 0, 0, 0, 0};   // B, H, W, K, hn of that call: a hint left by another problem shape is ignored
+    int shape[5] = {0, 0, 0, 0, 0};   // B, H, W, K, hn of that call: a hint left by another problem shape is ignored.
+                                      // The BATCH SIZE is not part of the shape that must match: a detector hands over a different number
+                                      // of crops with every frame; sums over the last call's images are scaled to this call's B
     bool tried = false;
 };
 StageHint g_hint[64];
@@ -253,6 +255,11 @@ StageHint *stage_hint_locked(hipStream_t st, bool allocate)
     return g->ratio ? g : nullptr;
 }
 
+bool hint_same_shape(const StageHint *g, const pvv_problem *p)
+{
+    return g->shape[1] == p->H && g->shape[2] == p->W && g->shape[3] == p->K && g->shape[4] == p->hn;
+}
+
 // A v3 call is about to leave its winners' ratios in the device's slot: record whose they are and hand out the array.
 float *stage_hint_claim(const pvv_problem *p, hipStream_t st)
 {
@@ -260,11 +267,14 @@ float *stage_hint_claim(const pvv_problem *p, hipStream_t st)
     StageHint *g = stage_hint_locked(st, true);
     if (!g) return nullptr;
     const int shape[5] = {p->B, p->H, p->W, p->K, p->hn};
-    if (memcmp(g->shape, shape, sizeof(shape)) != 0) {
+    if (!hint_same_shape(g, p)) {
         // another problem shape: what the array holds says nothing about this one -- until this call reports, no data
-        memcpy(g->shape, shape, sizeof(shape));
         for (int i = 0; i < p->B; ++i) g->ratio[i] = -2.f;
+    } else {
+        // more images than the last call had: the new slots hold nothing of this shape until this call reports
+        for (int i = g->n; i < p->B; ++i) g->ratio[i] = -2.f;
     }
+    memcpy(g->shape, shape, sizeof(shape));
     g->n = p->B;
     return g->ratio;
 }
@@ -277,10 +287,7 @@ float stage_hint_mean(const pvv_problem *p, hipStream_t st, float *max_tn = null
     std::lock_guard<std::mutex> lock(g_hint_mu);
     StageHint *g = stage_hint_locked(st, false);
     if (!g || g->n <= 0) return -1.f;
-    if (p) {
-        const int shape[5] = {p->B, p->H, p->W, p->K, p->hn};
-        if (memcmp(g->shape, shape, sizeof(shape)) != 0) return -1.f;
-    }
+    if (p && !hint_same_shape(g, p)) return -1.f;
     double sum = 0, stn = 0;
     int cnt = 0;
     float mt = 0.f;
@@ -293,7 +300,7 @@ float stage_hint_mean(const pvv_problem *p, hipStream_t st, float *max_tn = null
         stn += std::max(0.f, (float)r[kMaxBatchLds + i]);
     }
     if (max_tn) *max_tn = mt;
-    if (sum_tn && cnt) *sum_tn = stn;
+    if (sum_tn && cnt) *sum_tn = p ? stn * (double)p->B / (double)g->n : stn;   // (scaled to this call's batch size)
     return cnt ? (float)(sum / cnt) : -1.f;
 }
 
@@ -304,8 +311,7 @@ long long stage_hint_rest_chunks(const pvv_problem *p, hipStream_t st, uint32_t 
     std::lock_guard<std::mutex> lock(g_hint_mu);
     StageHint *g = stage_hint_locked(st, false);
     if (!g || g->n <= 0) return -1;
-    const int shape[5] = {p->B, p->H, p->W, p->K, p->hn};
-    if (memcmp(g->shape, shape, sizeof(shape)) != 0) return -1;
+    if (!hint_same_shape(g, p)) return -1;
     const volatile float *r = g->ratio;
     long long total = 0;
     constexpr int PC = 4 * kBfPixPerWave;
@@ -315,7 +321,7 @@ long long stage_hint_rest_chunks(const pvv_problem *p, hipStream_t st, uint32_t 
         if (nch >= kStageMinChunks)
             total += (nch / kStageM) * __builtin_popcount(rest_mask) + __builtin_popcount(rest_mask & ((1u << (nch % kStageM)) - 1u));
     }
-    return total;
+    return total * p->B / g->n;                                           // (scaled to this call's batch size)
 }
 
 // The break-even winner ratio, from one-process A/B measurements of whole calls on MI355X with the round-4 second launch

@@ -279,7 +279,8 @@ int pvv_stream_read_probe(const void *d_buf, size_t bytes, uint32_t *d_sink, voi
  * that mean reaches a threshold that depends on the problem's size (pvnet_vote.hip, stage_hint_threshold; DESIGN.md
  * 4.6-4.7).  The same array carries every image's tn, so the size that decides is the call's real work -- K * hn * sum(tn)
  * evaluations as the last call of this shape reported them (dense detector crops stage at a batch size where sparse full
- * frames do not) -- and B*K*hn*H*W, a proxy calibrated on frames with 2 % foreground, only while no call has reported.  The
+ * frames do not; "shape" = H, W, K, hn: the batch size may change from call to call, the sums are scaled to it) -- and
+ * B*K*hn*H*W, a proxy calibrated on frames with 2 % foreground, only while no call has reported.  The
  * hint lags by the calls in flight and only selects between two exact paths; with no data yet the proxy alone decides;
  * PVV_COUNT_STAGED / PVV_COUNT_FULL ignore it.  This query is for tests, benches and the curious: returns 1 and
  * the mean when data is there (0 and -1 otherwise), and the threshold of `p` (p may be NULL: -1; 2 = a problem with too

@@ -303,7 +303,7 @@ def test_auto_stages_dense_crops_by_their_real_work(synth, pkg, gpu):
     hn = 512
     for fg, want_staged in ((0.35, True), (0.02, False)):
         d = synth.make_batch(B=16, H=256, W=256, K=9, fg=fg, sigma=0.05, seed=300 + int(fg * 100), device=gpu)
-        d2 = synth.make_batch(B=15, H=256, W=256, K=9, fg=fg, sigma=0.05, seed=400, device=gpu)      # another shape: resets the hint
+        d2 = synth.make_batch(B=3, H=128, W=256, K=9, fg=fg, sigma=0.05, seed=400, device=gpu)       # another shape (H): resets the hint
         ext.ransac_voting_v3(d2["mask"], d2["vertex"], hn, 0.99, 5, 30000, None, None, 5, ext.SINGULAR_REFERENCE, count_kernel=ext.COUNT_AUTO)
 
         def v3(k):
@@ -319,6 +319,12 @@ def test_auto_stages_dense_crops_by_their_real_work(synth, pkg, gpu):
         assert all((r[5] > 0) == want_staged for r in ms), ms
         ref, got = v3(ext.COUNT_FULL), v3(ext.COUNT_AUTO)
         assert all(torch.equal(a, b) for a, b in zip(got[:3], ref[:3]))
+        # the batch size is not part of the shape that must match -- a detector hands over a different number of crops with every
+        # frame --: fewer or more crops are decided at once on the last call's per-image figures (scaled to the new batch size)
+        for Bn, first in ((11, want_staged), (21, want_staged)):
+            dn = synth.make_batch(B=Bn, H=256, W=256, K=9, fg=fg, sigma=0.05, seed=500 + Bn, device=gpu)
+            ms = [ext.stage_ms_in_pipeline([dn["mask"]], [dn["vertex"]], hn, 0.99, 5, 30000, 5, 1, ext.COUNT_AUTO)[0] for _ in range(2)]
+            assert (ms[0][5] > 0) == first and (ms[1][5] > 0) == want_staged, (Bn, ms)     # (each call completes before the next decides)
 
 
 def test_auto_follows_the_stage_hint(synth, pkg, gpu):
