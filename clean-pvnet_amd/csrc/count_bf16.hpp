@@ -143,6 +143,9 @@ struct StageArgs {
                           // (zeroed by k_compact_hyp; count_filter_runs.hpp)
     int sub_tenth;        // 1: the caller is estimate_voting_distribution_with_mean, which weighs every hypothesis whose ratio is
                           // within 0.1 of the best (P:262-264): the elimination bound is lowered accordingly (stage_bound)
+#ifdef PVV_STAMPS
+    long long *dbg;       // instrumented builds: the phase census of k_count_filter_runs (count_filter_runs.hpp)
+#endif
 };
 
 // The count a hypothesis must still be able to reach to matter.  ransac_voting_layer_v3 keeps the arg-max: L* itself.  The

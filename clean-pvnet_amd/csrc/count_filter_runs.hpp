@@ -38,6 +38,24 @@
 constexpr int kRunMaxChunks = 64;
 constexpr int kRunSlots = kBfMaxHt * 32;          // 512 staging slots
 
+// Phase census of this kernel, instrumented builds only (tools/build_variant.sh <name> -DPVV_TUNING -DPVV_STAMPS +
+// tools/census_filter.py): thread 0 of every block adds the shader cycles (s_memtime) between consecutive marks to one
+// of 10 phase accumulators in LDS and writes them, with its item / chunk / survivor / tile counts and its wall-clock
+// entry and exit, to dbg[16 * block ...] on exit (StageArgs.dbg, a member that exists only in such builds).
+#ifdef PVV_STAMPS
+#define PVV_FS_DECL() __shared__ long long s_fs[16]; long long fs_last = 0; \
+    if (threadIdx.x == 0) { for (int i_ = 0; i_ < 16; ++i_) s_fs[i_] = 0; s_fs[14] = wall_clock64(); fs_last = (long long)__builtin_readcyclecounter(); }
+#define PVV_FS(i) do { if (threadIdx.x == 0) { const long long t_ = (long long)__builtin_readcyclecounter(); s_fs[i] += t_ - fs_last; fs_last = t_; } } while (0)
+#define PVV_FS_ADD(i, n) do { if (threadIdx.x == 0) s_fs[i] += (n); } while (0)
+#define PVV_FS_OUT() do { if (sa.dbg && threadIdx.x == 0) { s_fs[15] = wall_clock64(); \
+    for (int i_ = 0; i_ < 16; ++i_) sa.dbg[(size_t)blockIdx.x * 16 + i_] = s_fs[i_]; } } while (0)
+#else
+#define PVV_FS_DECL() do { } while (0)
+#define PVV_FS(i) do { } while (0)
+#define PVV_FS_ADD(i, n) do { } while (0)
+#define PVV_FS_OUT() do { } while (0)
+#endif
+
 // B operand of slot i (see stage_hypothesis): the counters are NOT touched.
 __device__ __forceinline__ int stage_hypothesis_b(bf16x8 *sB, int i, float2 hp, float2 org)
 {
@@ -58,7 +76,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     const float2 *__restrict__ hyps /*[B,K,hn]*/, int *__restrict__ counts /*[B,K,hn]*/,
     const int *__restrict__ tn_arr, int B, int K, int hn, int cap, float thresh, Bf16Consts fc, int target_items, int run_r, StageArgs sa)
 {
-    __shared__ int run_end[kMaxBatchLds];           // inclusive prefix of the runs per image
+    // inclusive prefix of the runs per image: DYNAMIC shared memory, B ints (the host passes sizeof(int) * B).  Round 5: as a
+    // static kMaxBatchLds array it made the block's LDS 32 064 B -- 26 of the CU's 1280-byte allocation granules, so that only
+    // FOUR blocks fitted the 160 KB where the grid (5 per CU) and the register budget (96 VGPRs) were sized for five: a fifth of
+    // the blocks waited ~26 us for a slot (tools/census_filter.py: 1024 of 1280 blocks alive).  27 968 B + 4 B per image is 23
+    // granules at B = 64 and stays within 25 up to B = 1008.
+    extern __shared__ int run_end[];
     __shared__ int s_R, s_runs, s_gpi;
     __shared__ bf16x8 sB[kBfMaxHt * 64];            // B operands of the staged survivors (16 KB)
     __shared__ float4 sP[4 * kBfPixPerWave];        // per pixel: (nhx, nhy, c'x, c'y); nhx = NaN: can never vote  (8 KB)
@@ -72,6 +95,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     constexpr uint32_t REST = stage_rest_of(FIRST);  // the chunks the first launch left
     const int nhg = (hn + GH - 1) / GH;             // hypothesis groups per keypoint
     if (*sa.any_staged == 0) return;
+    PVV_FS_DECL();
 
     // ---- the item table: remaining chunks per image (0 for the images the first launch counted completely), the run
     //      length from their total, runs per image as an inclusive prefix.  Wave 0; every block derives the same table.
@@ -119,6 +143,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         if (lane == 0) { s_R = R; s_runs = carry; s_gpi = gpi; }
     }
     __syncthreads();
+    PVV_FS(0);                                                   // phase 0: entry -> item table built
     const int R = __builtin_amdgcn_readfirstlane(s_R);
     const int gpi = __builtin_amdgcn_readfirstlane(s_gpi), ngr = (nhg + gpi - 1) / gpi;   // groups per item, group ranges per keypoint
     const int per_run = K * ngr;
@@ -155,6 +180,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             lstar = stage_bound(__builtin_amdgcn_readfirstlane(full), tn, sa.sub_tenth);
         }
 
+        PVV_FS(1);                                               // phase 1: item decode, tn, leaders -> L*
+        PVV_FS_ADD(10, 1);
         for (int g = g_begin; g < g_end;) {
             // ================= a pass: the survivors of groups gp0 .. g-1 (as many consecutive groups as fit the slots)
             const int gp0 = g;
@@ -197,6 +224,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 __syncthreads();                                 // s_keep is free again; the slots are visible
                 if (!fits) break;                                // group g opens the next pass
             }
+            PVV_FS(2);                                           // phase 2: counters + miss read, keep predicate, survivor compaction
             if (ns == 0) continue;                               // nobody of these groups can still reach L*
 
             for (int j = j0; j < j1 && ns > 0; ++j) {
@@ -252,6 +280,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                     if (i < ns_pad) far |= stage_hypothesis_b(sB, i, hp[q], org);
                 }
                 far = __syncthreads_or(far);
+                PVV_FS(3);                                       // phase 3: the chunk's loads, pixel records, B staging, barrier
+                PVV_FS_ADD(11, 1);
+                PVV_FS_ADD(12, ns);
                 const float C1 = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
                 const float eps = fc.eps0 + fc.eps_c * C1;
                 const float epsw = __builtin_fmaf(fc.beta * 1.02f, C1, eps);   // band half-width at |h'| = 0
@@ -293,6 +324,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 }
                 const int nht = ns_pad >> 5, nslot = ns;
                 const float2 *hyp_p = hyp_k + gp0 * GH;           // slot s holds hypothesis hyp_p[sCnt[s] >> 16]
+                PVV_FS(4);                                       // phase 4: A operands
+                PVV_FS_ADD(13, nht * ntile_w);
 
                 if (__builtin_expect(far, 0)) {
                     // some survivor is non-finite / astronomically far: exact loop (K:100-125)
@@ -384,7 +417,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                         if (inl) atomicAdd(&sCnt[ht * 32 + col], inl);    // LDS: 2 lanes x 4 waves per slot
                     }
                 }
+                PVV_FS(5);                                       // phase 5: the matrix-core loop (wave 0's own)
                 __syncthreads();                                 // the chunk's counts are complete; sB / sP are free
+                PVV_FS(6);                                       // phase 6: waiting for the other waves' loops
                 // ---- COOPERATIVE progressive elimination.  Every survivor's misses of this chunk -- pixels that are exactly
                 //      decided NOT to be its inliers -- go to miss[h], shared by all the runs of the (image, keypoint); the
                 //      value the atomic returns counts what every run has proven so far.  full(h) = partial(h) + R - (all its
@@ -441,6 +476,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                         __syncthreads();
                     }
                 }
+                PVV_FS(7);                                       // phase 7: elimination step (miss atomics, re-compaction, barriers)
             }
             // ---- flush the run's counts of the survivors
             __syncthreads();
@@ -448,6 +484,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 const int v = sCnt[i];
                 if (v & 0xffff) atomicAdd(&cnt_k[gp0 * GH + (int)((unsigned)v >> 16)], v & 0xffff);
             }
+            PVV_FS(8);                                           // phase 8: flush
         }
     }
+    PVV_FS(9);
+    PVV_FS_OUT();
 }

@@ -84,6 +84,24 @@ struct Layout {
 bool use_bf16_count(const pvv_problem *p);
 bool may_stage(const pvv_problem *p);
 
+// Subsampling inside k_compact_hyp (no k_tile_subsample launch): only for images of <= kFuseSubTiles tiles and only when
+// subsampling is unlikely -- max_num at least 1/16 of the image (30000 of 307200) -- and (make_front) only with the device RNG.
+bool fuse_sub_shape(const pvv_problem *p, int T)
+{
+    return T <= kFuseSubTiles && (long long)p->max_num * 16 >= (long long)p->H * p->W;
+}
+
+// Does a call of this problem ever STORE per-pixel subsample draws (tile_draw: 4 B per pixel of the batch)?  Only the
+// separate subsample pass reads them (k_tile_subsample; make_front: want_draws).  Whether that pass runs depends on pointer
+// arguments the workspace query cannot see -- injected index pairs or draws switch the fused subsampling off -- unless the
+// caller promises the device RNG (PVV_FLAG_DEVICE_RNG): then draws are stored only for images too large to fuse, and never
+// when no mask of this shape can exceed max_num (the largest foreground_num: 255 per pixel, P:126).
+bool may_store_draws(const pvv_problem *p, int T)
+{
+    if ((long long)p->max_num >= 255ll * p->H * p->W) return false;
+    return !((p->flags & PVV_FLAG_DEVICE_RNG) && fuse_sub_shape(p, T));
+}
+
 Layout make_layout(const pvv_problem *p)
 {
     Layout L;
@@ -93,7 +111,7 @@ Layout make_layout(const pvv_problem *p)
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     L.tiles = take(sizeof(uint32_t) * (size_t)p->B * L.T);
     L.tile_list = take(sizeof(unsigned short) * (size_t)p->B * L.T * kTile);
-    L.tile_draw = take(sizeof(float) * (size_t)p->B * L.T * kTile);
+    L.tile_draw = may_store_draws(p, L.T) ? take(sizeof(float) * (size_t)p->B * L.T * kTile) : 0;   // (0: not reserved)
     L.tn = take(sizeof(int) * (size_t)p->B);
     L.surv = take(sizeof(int) * (size_t)p->B * kSurvCap);
     L.coords = take(sizeof(float2) * (size_t)p->B * p->cap);
@@ -116,7 +134,8 @@ int validate(const pvv_problem *p)
     if (p->B > kMaxBatchLds) return fail(PVV_E_ARG, "B > 1024: split the batch");
     if (((long long)p->H * p->W + kTile - 1) / kTile > kMaxTiles) return fail(PVV_E_ARG, "H*W too large (more than 16000 tiles of 2048 pixels)");
     if ((long long)p->K * p->hn >= (1ll << 23)) return fail(PVV_E_ARG, "K*hn must be < 2^23");
-    if (p->count_kernel < PVV_COUNT_AUTO || p->count_kernel > PVV_COUNT_STAGED) return fail(PVV_E_ARG, "unknown count_kernel");
+    if (p->count_kernel < PVV_COUNT_AUTO || p->count_kernel > PVV_COUNT_STAGED_ESTIMATE) return fail(PVV_E_ARG, "unknown count_kernel");
+    if (p->flags & ~PVV_FLAG_DEVICE_RNG) return fail(PVV_E_ARG, "unknown bits in flags");
     if (p->mask_elem_size != 1 && p->mask_elem_size != 2 && p->mask_elem_size != 4 &&
         p->mask_elem_size != 8)
         return fail(PVV_E_ARG, "mask_elem_size must be 1, 2, 4 or 8");
@@ -189,7 +208,7 @@ constexpr double kStageProxyFg = 0.02;      // tn / (H*W) of the frames the prox
 bool may_stage(const pvv_problem *p)
 {
     if (!use_bf16_count(p) || p->count_kernel == PVV_COUNT_FULL) return false;
-    if (p->count_kernel == PVV_COUNT_STAGED) return true;
+    if (p->count_kernel == PVV_COUNT_STAGED || p->count_kernel == PVV_COUNT_STAGED_ESTIMATE) return true;
     // cap bounds tn: with fewer than 8 chunks of rows reserved per image nothing can ever be staged (the reference's default
     // call, max_num = 100: 244 rows)
     const double rows = std::min((double)p->H * p->W, (double)p->cap);
@@ -463,6 +482,9 @@ int launch_staged(const StagedLaunch &a)
     sa.any_staged = lead + (size_t)p->B * p->K * 8;
     sa.miss = (int *)(ws + L.miss);
     sa.sub_tenth = a.sub_tenth;
+#ifdef PVV_STAMPS
+    sa.dbg = tuning_ptr("PVV_DBG_PTR_FILTER");                    // phase census of the second launch (tools/census_filter.py)
+#endif
     hipLaunchKernelGGL((k_count_bf16<kCountFirst, FIRST>), dim3(a.per_cu_first * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
                        p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, a.target_first, a.dbg, sa);
     if (int e = check_launch("k_count_bf16<first>")) return e;
@@ -491,7 +513,7 @@ int launch_staged(const StagedLaunch &a)
     // round 3's items one group each -- config 5 at B = 2, runs of one chunk: round 3's kernel +2.3 % per call.)
     const bool runs = rest < 0 || rest * p->K >= 2ll * a.target_filter || p->hn > 512;
     if (tuning_int("PVV_FILTER_OLD", runs ? 0 : 1) == 0) {
-        hipLaunchKernelGGL(k_count_filter_runs<FIRST>, dim3(tuning_int("PVV_GRID_PER_CU_FILTER", 5) * num_cus()), dim3(kBlock), 0, st, coords, dirs,
+        hipLaunchKernelGGL(k_count_filter_runs<FIRST>, dim3(tuning_int("PVV_GRID_PER_CU_FILTER", 5) * num_cus()), dim3(kBlock), sizeof(int) * (size_t)p->B, st, coords, dirs,
                            hyps, counts, tn, p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, a.target_filter, tuning_int("PVV_RUN_R", 0), sa);
         return check_launch("k_count_filter_runs");
     }
@@ -578,32 +600,32 @@ CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
     return a;
 }
 
-// The ESTIMATE in stages (round 4, measured and NOT taken by AUTO): estimate_voting_distribution_with_mean weighs every hypothesis
+// The ESTIMATE in stages (round 4, measured and never taken by AUTO): estimate_voting_distribution_with_mean weighs every hypothesis
 // whose ratio lies within 0.1 of the best (P:262-264), so its count pass may drop what provably falls below that window
 // (stage_bound, count_bf16.hpp) when nobody asked for the counts themselves.  Covariances and PnP weights are bit-identical to the
-// full pass (tests/test_gpu_staged.py), a third of the hypothesis-tile work goes away (42 % of the hypotheses carry weight, 74 %
-// survive a quarter of the pixels, the pooled misses drop the rest as they go) -- and the call does not get reliably faster.  4096
-// hypotheses at 480x640, K = 9, staged vs full (tools/estimate_ab.py, profiles/r04_experiments.txt): with items that walked all
-// eight hypothesis groups in passes 1.60 vs 1.43 ms at B = 64, 0.293 vs 0.221 at B = 8, 0.197 vs 0.053 at B = 1; with items cut by
-// groups (count_filter_runs.hpp) 1.437 vs 1.402 at B = 64, **0.682 vs 0.741 at B = 32, 0.382 vs 0.421 at B = 16**, 0.225 vs 0.219 at
-// B = 8, 0.074 vs 0.054 at B = 1; config 5's 2048 at B = 16: 1.54 vs 1.54.  The full kernel builds a chunk's pixel operands once
-// for all eight groups and runs VALU-saturated (busy 1.00); the second launch pays its per-chunk prologue per 512 survivors and
-// runs at ~0.55.  PVV_COUNT_STAGED still forces it (the tests' cross-check of the bound).
-// (The lead at B = 16 ... 32 was the full pass's item quantisation, not the elimination: with long items split to three generations'
-// worth -- count_bf16.hpp -- the full estimate takes 0.376 ms at B = 16 and 0.707 at B = 32, and the staged one leads nowhere but
-// B = 32, by 4 %.)
-bool est_stage_auto(const pvv_problem *) { return false; }
-
+// full pass (tests/test_gpu_staged.py), a third of the hypothesis-tile work goes away -- and the call does not get reliably faster
+// (4096 hypotheses at 480x640, K = 9, staged vs full: 1.437 vs 1.402 ms at B = 64, 0.225 vs 0.219 at B = 8, 0.074 vs 0.054 at B = 1;
+// profiles/r04_experiments.txt): the full kernel builds a chunk's pixel operands once for all eight groups and runs VALU-saturated,
+// the second launch pays its per-chunk prologue per 512 survivors.  ABI v8: only PVV_COUNT_STAGED_ESTIMATE takes this path (the
+// tests' cross-check of the bound); PVV_COUNT_STAGED means v3 alone again.
+//
 // kind: 0 = the pass must deliver every count (the estimate when its counts are an output, the fused un_pnp pass);
 //       1 = ransac_voting_layer_v3 proper, which keeps the arg-max and may count in stages;
 //       2 = the estimate without a counts output, which may count in stages against its own bound
-int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, int kind)
+// -> 0: full pass, 1: v3 in stages, 2: the estimate in stages.  Decided ONCE per call, before the front kernels are launched:
+// k_compact_hyp zeroes the miss counters and leader words only for a call that will stage.
+int decide_staged(const pvv_problem *p, const Layout &L, hipStream_t st, int kind)
+{
+    if (!may_stage(p) || L.lead == 0) return 0;
+    if (kind == 1 && stage_hint_allows(p, st)) return 1;
+    if (kind == 2 && p->count_kernel == PVV_COUNT_STAGED_ESTIMATE) return 2;
+    return 0;
+}
+
+int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, int staged)
 {
     if (p->ev_count_begin && hipEventRecord((hipEvent_t)p->ev_count_begin, st) != hipSuccess)
         return fail(PVV_E_ARG, "ev_count_begin is not a valid hipEvent_t");
-    int staged = 0;
-    if (kind == 1 && may_stage(p) && L.lead != 0 && stage_hint_allows(p, st)) staged = 1;
-    if (kind == 2 && may_stage(p) && L.lead != 0 && (p->count_kernel == PVV_COUNT_STAGED || est_stage_auto(p))) staged = 2;
     const int e = use_bf16_count(p) ? launch_count_bf16(p, L, ws, st, staged) : launch_count(planar_count_args(p, L, ws), st);
     if (e) return e;
     if (p->ev_count_end && hipEventRecord((hipEvent_t)p->ev_count_end, st) != hipSuccess)
@@ -674,7 +696,7 @@ Front make_front(const pvv_problem *p, int mode, const void *d_mask, const float
     // subsampling is unlikely -- max_num at least 1/16 of the image (30000 of 307200) -- and only with the device RNG:
     // injected index pairs address rows of the SUBSAMPLED list, which the hypothesis blocks can read off the tile lists
     // only after k_tile_subsample has rewritten them.
-    m.fuse_sub = (L.T <= kFuseSubTiles && (long long)p->max_num * 16 >= (long long)p->H * p->W && !d_idxs && !d_idxs2) ? 1 : 0;
+    m.fuse_sub = (fuse_sub_shape(p, L.T) && !d_idxs && !d_idxs2) ? 1 : 0;
     // largest possible foreground_num: the sum of byte values (P:126), of class indices (fused argmax) or of ones (P:208)
     const long long max_weight = mode == 1 ? 1 : (d_seg ? (p->seg_classes > 1 ? p->seg_classes - 1 : 1) : 255);
     f.can_subsample = (long long)p->max_num < max_weight * (long long)p->H * p->W;
@@ -785,11 +807,11 @@ SideStream *side_get(hipStream_t st)
     return g->ok ? g : nullptr;
 }
 
-bool side_fork(hipStream_t st, hipStream_t *side, hipEvent_t *join)
+// Fork: `side` waits for everything enqueued on `st` so far.  Call with g_side_mu held (SideFork below): the ring slot, the
+// fork record and the side stream's wait are one step, and so are the kernel launched on the side stream and its join record --
+// two threads forking at once would otherwise interleave records and launches on the one side stream.
+bool side_fork_locked(SideStream *g, hipStream_t st, hipStream_t *side, hipEvent_t *join)
 {
-    SideStream *g = side_get(st);
-    if (!g) return false;
-    std::lock_guard<std::mutex> lock(g_side_mu);
     const int i = g->next;
     g->next = (i + 1) & 7;
     if (hipEventRecord(g->fork[i], st) != hipSuccess || hipStreamWaitEvent(g->st, g->fork[i], 0) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -798,22 +820,47 @@ bool side_fork(hipStream_t st, hipStream_t *side, hipEvent_t *join)
     return true;
 }
 
+// Joins the side stream back into the caller's stream on EVERY way out of run_front once work has been forked (an
+// error return between fork and join used to leave the side kernel unordered with `stream` while the caller already held
+// an error code).  The join event of a ring slot may be re-recorded by a later fork before this wait is issued: both
+// records are on the one in-order side stream, so waiting for the later one still covers this call's kernel.
+struct SideJoin {
+    hipStream_t st = nullptr;
+    hipEvent_t join = nullptr;
+    bool armed = false;
+    int finish()                                                   // explicit join on the success path: its failure is an error
+    {
+        if (!armed) return PVV_OK;
+        armed = false;
+        return hipStreamWaitEvent(st, join, 0) == hipSuccess ? PVV_OK : fail(PVV_E_ARG, "side stream: hipStreamWaitEvent failed");
+    }
+    ~SideJoin()
+    {
+        if (armed && hipStreamWaitEvent(st, join, 0) != hipSuccess) (void)hipGetLastError();   // (the call is failing already)
+    }
+};
+
 // mask scan + (subsample) + compaction and hypotheses + counting, shared by both layers.
 int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d_vertex,
               const int32_t *d_idxs, const float *d_selection, char *ws, const Layout &L,
               hipStream_t st, int32_t *d_tn, const float *d_seg = nullptr, int64_t *d_mask_out = nullptr,
               const int32_t *d_idxs2 = nullptr, int hn_first = -1, uint32_t stream_first = 1u, uint32_t stream_rest = 3u,
-              int stage_kind = 0 /*launch_count_any's kind*/)
+              int stage_kind = 0 /*decide_staged's kind*/)
 {
+    if ((p->flags & PVV_FLAG_DEVICE_RNG) && (d_idxs || d_idxs2 || d_selection))
+        return fail(PVV_E_ARG, "PVV_FLAG_DEVICE_RNG promises d_idxs = d_idxs_est = d_selection = NULL");
     Front f = make_front(p, mode, d_mask, d_vertex, d_idxs, d_selection, ws, L, d_tn, d_seg, d_mask_out, d_idxs2,
                          hn_first, stream_first, stream_rest);
-    if (stage_kind == 0) f.h.miss = nullptr;                        // a pass that cannot count in stages neither reads nor zeroes them
+    if (f.m.want_draws && L.tile_draw == 0) return fail(PVV_E_WORKSPACE, "workspace holds no draw storage for this call");   // (cannot happen: may_store_draws)
+    // whether the count pass runs in stages is decided HERE, once: a call that will not stage neither zeroes nor reads the
+    // miss counters and leader words (k_compact_hyp would otherwise clear B*K*hn words for nothing on every AUTO call)
+    const int staged = decide_staged(p, L, st, stage_kind);
+    if (!staged) { f.h.miss = nullptr; f.h.lead = nullptr; }
     if (int e = mark(p, PVV_MARK_BEGIN, st)) return e;
-    hipStream_t side = nullptr;
-    hipEvent_t join = nullptr;
-    bool deferred = false;
+    SideJoin sj;
     // no side stream to be had (the caller's stream is being captured, ...): the scan writes the mask itself
-    const bool defer_mask = f.mask_deferred && tuning_int("PVV_MASK_DEFER", 1) != 0 && side_get(st) != nullptr;
+    SideStream *sg = (f.mask_deferred && tuning_int("PVV_MASK_DEFER", 1) != 0) ? side_get(st) : nullptr;
+    const bool defer_mask = sg != nullptr;
     if (int e = run_scan(p, f, ws, L, st, !defer_mask)) return e;
     if (!f.m.fuse_sub && f.can_subsample) {
         hipLaunchKernelGGL(k_tile_subsample, dim3(L.T, p->B), dim3(kBlock), 0, st, f.m, (uint32_t *)(ws + L.tiles),
@@ -830,17 +877,29 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
     if (defer_mask) {
         // forked BEHIND the compaction (measured: forked behind the scan, the 157 MB of stores cost the latency-bound
         // compaction +14 us at B = 64 and the count pass +9; the count pass alone is 130 us of mostly VALU work)
-        deferred = side_fork(st, &side, &join);
-        const hipStream_t ms = deferred ? side : st;                // no side stream: the same kernel, in line
+        std::lock_guard<std::mutex> lock(g_side_mu);                // fork, launch and join record: one step (see side_fork_locked)
+        hipStream_t side = nullptr;
+        hipEvent_t join = nullptr;
+        const bool forked = side_fork_locked(sg, st, &side, &join);
+        const hipStream_t ms = forked ? side : st;                  // the fork failed: the same kernel, in line
         const long long total = (long long)L.T * p->B;
         const int grid = (int)std::min<long long>(total, (long long)tuning_int("PVV_MASK_GRID_PER_CU", 2) * num_cus());
         hipLaunchKernelGGL(k_mask_from_lists, dim3(grid), dim3(kBlock), 0, ms, (const uint32_t *)(ws + L.tiles),
                            (const unsigned short *)(ws + L.tile_list), f.mask_deferred, L.T, p->H * p->W, (int)total);
-        if (int e = check_launch("k_mask_from_lists")) return e;
-        if (deferred && hipEventRecord(join, side) != hipSuccess) return fail(PVV_E_ARG, "side stream: hipEventRecord failed");
+        const int le = check_launch("k_mask_from_lists");
+        if (forked) {
+            // whatever happened to the launch, the side stream now holds this call's fork: join it back on every exit
+            if (hipEventRecord(join, side) == hipSuccess) { sj.st = st; sj.join = join; sj.armed = true; }
+            else {
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(side);                   // no event to wait for: drain the side stream instead
+                if (!le) return fail(PVV_E_ARG, "side stream: hipEventRecord failed");
+            }
+        }
+        if (le) return le;
     }
-    if (int e = launch_count_any(p, L, ws, st, stage_kind)) return e;
-    if (deferred && hipStreamWaitEvent(st, join, 0) != hipSuccess) return fail(PVV_E_ARG, "side stream: hipStreamWaitEvent failed");
+    if (int e = launch_count_any(p, L, ws, st, staged)) return e;
+    if (int e = sj.finish()) return e;
     return mark(p, PVV_MARK_COUNT, st);
 }
 
@@ -862,6 +921,47 @@ int check_ptrs(const pvv_problem *p, const void *mask, const void *vertex, void 
 // =============================================================================================
 PVV_EXPORT int pvv_abi_version(void) { return PVV_ABI_VERSION; }
 PVV_EXPORT const char *pvv_last_error(void) { return g_err; }
+
+// ABI v8: give back what the library created behind the caller's back (see the header).  Everything is released even when
+// a call fails; the first error is reported.
+PVV_EXPORT int pvv_shutdown(void)
+{
+    int rc = PVV_OK;
+    auto note = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (rc == PVV_OK) { snprintf(g_err, sizeof(g_err), "pvv_shutdown: %s: %s", what, hipGetErrorString(e)); rc = (int)e; }
+        }
+    };
+    int cur = -1;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    if (!have_cur) (void)hipGetLastError();
+    {
+        std::lock_guard<std::mutex> lock(g_side_mu);
+        for (int dev = 0; dev < 64; ++dev) {
+            SideStream *g = &g_side[dev];
+            if (g->tried) {
+                if (have_cur && hipSetDevice(dev) != hipSuccess) (void)hipGetLastError();
+                if (g->st) { note(hipStreamSynchronize(g->st), "hipStreamSynchronize(side stream)"); note(hipStreamDestroy(g->st), "hipStreamDestroy"); }
+                for (int i = 0; i < 8; ++i) {
+                    if (g->fork[i]) note(hipEventDestroy(g->fork[i]), "hipEventDestroy");
+                    if (g->join[i]) note(hipEventDestroy(g->join[i]), "hipEventDestroy");
+                }
+            }
+            *g = SideStream();
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_hint_mu);
+        for (int dev = 0; dev < 64; ++dev) {
+            StageHint *g = &g_hint[dev];
+            if (g->ratio) note(hipHostFree(g->ratio), "hipHostFree(stage hint)");
+            *g = StageHint();
+        }
+    }
+    if (have_cur && hipSetDevice(cur) != hipSuccess) (void)hipGetLastError();
+    return rc;
+}
 
 PVV_EXPORT int pvv_stage_hint_query(float *mean_ratio, float *threshold, const pvv_problem *p, void *stream)
 {
@@ -1047,7 +1147,7 @@ PVV_EXPORT int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace, s
         if (e == hipSuccess && L.miss) e = hipMemsetAsync(ws + L.miss, 0, sizeof(int) * (size_t)p->B * p->K * p->hn, st);
         if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     }
-    return launch_count_any(p, L, ws, st, v3);
+    return launch_count_any(p, L, ws, st, decide_staged(p, L, st, v3));
 }
 
 // ---- streaming-read probe (bench aid; SURVEY 8(d): what a read-once stream reaches on this box) ------------------

@@ -229,6 +229,26 @@ const float *opt_selection(const std::optional<at::Tensor> &sel, const at::Tenso
     return t.data_ptr<float>();
 }
 
+// ABI v8: with nothing injected the device RNG draws everything -- the library then knows before the call that no per-pixel
+// subsample draw is ever stored for images small enough to subsample inside the compaction kernel, and leaves that storage
+// (4 B per pixel of the batch) out of the workspace.  Call before make_workspace.
+void promise_device_rng(pvv_problem &p, const std::optional<at::Tensor> &idxs, const std::optional<at::Tensor> &idxs2,
+                        const std::optional<at::Tensor> &selection)
+{
+    if (!idxs.has_value() && !idxs2.has_value() && !selection.has_value()) p.flags |= PVV_FLAG_DEVICE_RNG;
+}
+
+// `out` (optional): the caller's [b,vn,2] float32 result buffer -- e.g. this rank's rows of a persistent all_gather buffer
+// (clean_pvnet_amd.dist.GatherBuffer), so that the exchange needs no copy -- instead of a fresh tensor
+at::Tensor result_buffer(const std::optional<at::Tensor> &out, const pvv_problem &p, const at::Tensor &vertex)
+{
+    if (!out.has_value()) return at::empty({p.B, p.K, 2}, vertex.options());
+    check_dev(*out, "out", at::kFloat);
+    same_device(vertex, *out, "out");
+    TORCH_CHECK(out->dim() == 3 && out->size(0) == p.B && out->size(1) == p.K && out->size(2) == 2, "out must be [b,vn,2] = [", p.B, ",", p.K, ",2]");
+    return *out;
+}
+
 at::Tensor make_workspace(const pvv_problem &p, const at::Tensor &like)
 {
     size_t n = pvv_workspace_bytes(&p);
@@ -241,7 +261,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> ransac_voting_v3(
     at::Tensor mask, at::Tensor vertex, int64_t round_hyp_num, double inlier_thresh, int64_t min_num,
     int64_t max_num, std::optional<at::Tensor> idxs, std::optional<at::Tensor> selection, int64_t seed,
     int64_t singular_policy, int64_t first_image, int64_t count_kernel, std::optional<at::Tensor> status,
-    std::optional<int64_t> cap)
+    std::optional<int64_t> cap, std::optional<at::Tensor> out_buf)
 {
     const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num,
@@ -261,8 +281,9 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> ransac_voting_v3(
     }
     const int32_t *ip = opt_idxs(idxs, vertex, p);
     const float *sp = opt_selection(selection, vertex, p);
+    promise_device_rng(p, idxs, std::nullopt, selection);
     at::Tensor ws = make_workspace(p, vertex);
-    auto out = at::empty({p.B, p.K, 2}, vertex.options());
+    auto out = result_buffer(out_buf, p, vertex);
     auto win = at::empty({p.B, p.K}, vertex.options().dtype(at::kInt));
     auto tn = at::empty({p.B}, vertex.options().dtype(at::kInt));
     ok(pvv_ransac_voting_v3(&p, mask.data_ptr(), vertex.data_ptr<float>(), ip, sp, ws.data_ptr(),
@@ -294,6 +315,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_v3(
     cap_for_selection(selection, p);
     const int32_t *ip = opt_idxs(idxs, vertex, p);
     const float *sp = opt_selection(selection, vertex, p);
+    promise_device_rng(p, idxs, std::nullopt, selection);
     at::Tensor ws = make_workspace(p, vertex);
     auto out = at::empty({p.B, p.K, 2}, vertex.options());
     auto win = at::empty({p.B, p.K}, vertex.options().dtype(at::kInt));
@@ -331,6 +353,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tenso
     pe.hn = (int32_t)hyp_est;
     const int32_t *ie = opt_idxs(idxs_est, vertex, pe);
     const float *sp = opt_selection(selection, vertex, p);
+    promise_device_rng(p, idxs, idxs_est, selection);
     const size_t n = pvv_workspace_bytes_un_pnp(&p, (int32_t)hyp_est);
     TORCH_CHECK(n > 0, "invalid voting problem: ", pvv_last_error());
     at::Tensor ws = at::empty({(int64_t)n}, vertex.options().dtype(at::kByte));
@@ -365,6 +388,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> estimate_
                 "mean must be [b,vn,2]");
     const int32_t *ip = opt_idxs(idxs, vertex, p);
     const float *sp = opt_selection(selection, vertex, p);
+    promise_device_rng(p, idxs, std::nullopt, selection);
     at::Tensor ws = make_workspace(p, vertex);
     auto cov = at::empty({p.B, p.K, 2, 2}, vertex.options());
     auto tn = at::empty({p.B}, vertex.options().dtype(at::kInt));
@@ -404,6 +428,7 @@ std::vector<double> count_kernel_ms_in_pipeline(std::vector<at::Tensor> masks, s
                                      seed + r);
         p.ev_count_begin = (void *)ev[2 * r];
         p.ev_count_end = (void *)ev[2 * r + 1];
+        p.flags |= PVV_FLAG_DEVICE_RNG;
         at::Tensor ws = make_workspace(p, vertex);
         auto out = at::empty({p.B, p.K, 2}, vertex.options());
         ok(pvv_ransac_voting_v3(&p, mask.data_ptr(), vertex.data_ptr<float>(), nullptr, nullptr, ws.data_ptr(),
@@ -465,6 +490,7 @@ std::vector<std::vector<double>> stage_ms_in_pipeline(std::vector<at::Tensor> ma
         // inner_marks = false: no records INSIDE the count pass (each costs ~2 us): its duration is then what rocprofv3 sees
         if (!inner_marks) marks[PVV_MARK_STAGE0] = marks[PVV_MARK_PRUNE0] = nullptr;
         p.ev_marks = marks.data();
+        p.flags |= PVV_FLAG_DEVICE_RNG;
         at::Tensor ws = make_workspace(p, vertex);
         auto out = at::empty({p.B, p.K, 2}, vertex.options());
         if (estimate) {      // estimate_voting_distribution_with_mean with round_hyp_num hypotheses in total (mean = zeros: timing only)
@@ -525,12 +551,15 @@ void stream_read_probe(at::Tensor buf, at::Tensor sink)
 // Re-run only the inlier-count kernel on the state a previous ransac_voting_v3 call left in `ws`
 // (bench.py brackets this with HIP events to get the dominant kernel's duration).
 void rerun_count_kernel(at::Tensor mask, at::Tensor vertex, int64_t hn, double inlier_thresh, int64_t min_num,
-                        int64_t max_num, at::Tensor ws, bool zero_counts, int64_t count_kernel, std::optional<int64_t> cap)
+                        int64_t max_num, at::Tensor ws, bool zero_counts, int64_t count_kernel, std::optional<int64_t> cap, bool device_rng)
 {
     const c10::DeviceGuard device_guard(vertex.device());   // launch on the tensors' GPU, whatever the current device is
     pvv_problem p = make_problem(mask, vertex, hn, inlier_thresh, min_num, max_num, 0, 0);
     p.count_kernel = (int32_t)count_kernel;
-    // the workspace offsets depend on cap: a workspace made with ransac_voting_v3(..., cap=) needs the same value here
+    // the workspace offsets depend on the flags the call that made `ws` carried: ransac_voting_v3 promises the device RNG
+    // (PVV_FLAG_DEVICE_RNG: no draw storage) exactly when neither idxs nor selection was injected -- say so here
+    if (device_rng) p.flags |= PVV_FLAG_DEVICE_RNG;
+    // ... and on cap: a workspace made with ransac_voting_v3(..., cap=) needs the same value here
     if (cap.has_value()) {
         TORCH_CHECK(*cap >= 1 && *cap <= (int64_t)p.H * p.W, "cap must be in [1, H*W]");
         p.cap = (int32_t)*cap;
@@ -559,7 +588,21 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("ransac_voting_v3", &ransac_voting_v3, "batched ransac_voting_layer_v3", py::arg("mask"), py::arg("vertex"),
           py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"), py::arg("idxs"),
           py::arg("selection"), py::arg("seed"), py::arg("singular_policy"), py::arg("first_image") = 0,
-          py::arg("count_kernel") = 0, py::arg("status") = py::none(), py::arg("cap") = py::none());
+          py::arg("count_kernel") = 0, py::arg("status") = py::none(), py::arg("cap") = py::none(), py::arg("out") = py::none());
+    m.def("shutdown", []() { ok(pvv_shutdown(), "pvv_shutdown"); },
+          "pvv_shutdown: release the library's per-device side streams, events and pinned stage-hint arrays; forget every hint");
+    m.def("workspace_bytes", [](int64_t B, int64_t H, int64_t W, int64_t K, int64_t hn, int64_t max_num, int64_t mask_elem_size,
+                                int64_t count_kernel, bool device_rng) {
+              pvv_problem p;
+              memset(&p, 0, sizeof(p));
+              p.B = (int32_t)B; p.H = (int32_t)H; p.W = (int32_t)W; p.K = (int32_t)K; p.hn = (int32_t)hn;
+              p.mask_elem_size = (int32_t)mask_elem_size; p.min_num = 5; p.max_num = (int32_t)max_num;
+              p.cap = pvv_default_cap(p.H, p.W, p.max_num); p.inlier_thresh = 0.99f; p.count_kernel = (int32_t)count_kernel;
+              p.flags = device_rng ? PVV_FLAG_DEVICE_RNG : 0;
+              return (int64_t)pvv_workspace_bytes(&p);
+          }, "pvv_workspace_bytes for a contiguous problem (host-only: no GPU needed)", py::arg("B"), py::arg("H"), py::arg("W"),
+          py::arg("K"), py::arg("hn"), py::arg("max_num") = 30000, py::arg("mask_elem_size") = 8, py::arg("count_kernel") = 0,
+          py::arg("device_rng") = true);
     m.def("decode_keypoint_v3", &decode_keypoint_v3, "argmax(seg) fused with batched ransac_voting_layer_v3",
           py::arg("seg"), py::arg("vertex"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"),
           py::arg("max_num"), py::arg("idxs"), py::arg("selection"), py::arg("seed"), py::arg("singular_policy"),
@@ -575,7 +618,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("selection"), py::arg("seed"), py::arg("want_hyp"), py::arg("first_image") = 0, py::arg("count_kernel") = 0);
     m.def("rerun_count_kernel", &rerun_count_kernel, "re-launch the inlier-count pass (profiling aid)", py::arg("mask"),
           py::arg("vertex"), py::arg("hn"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"), py::arg("ws"),
-          py::arg("zero_counts"), py::arg("count_kernel") = 0, py::arg("cap") = py::none());
+          py::arg("zero_counts"), py::arg("count_kernel") = 0, py::arg("cap") = py::none(), py::arg("device_rng") = true);
     m.def("stage_ms_in_pipeline", &stage_ms_in_pipeline,
           "per-stage durations inside full v3 calls, HIP events at the stage boundaries (profiling aid)", py::arg("masks"),
           py::arg("vertices"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"),
@@ -601,6 +644,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.attr("COUNT_EXACT") = (int)PVV_COUNT_EXACT;
     m.attr("COUNT_FULL") = (int)PVV_COUNT_FULL;
     m.attr("COUNT_STAGED") = (int)PVV_COUNT_STAGED;
+    m.attr("COUNT_STAGED_ESTIMATE") = (int)PVV_COUNT_STAGED_ESTIMATE;
     m.attr("STATUS_SKIPPED") = (int)PVV_STATUS_SKIPPED;
     m.attr("STATUS_SUBSAMPLED") = (int)PVV_STATUS_SUBSAMPLED;
     m.attr("STATUS_TRUNCATED") = (int)PVV_STATUS_TRUNCATED;

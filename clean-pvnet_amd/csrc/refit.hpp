@@ -135,7 +135,9 @@ __global__ __launch_bounds__(64) void k_finalize_v3(const int *__restrict__ tn_a
     const int b = blockIdx.x;
     if (threadIdx.x == 0) any_singular = 0;
     __syncthreads();
-    const bool skipped = tn_arr[b] <= 0;
+    // skipped image (tn <= 0): k_select_refit left win_ratio = -1 and zero partial sums -- read with the sums, in ONE round trip
+    // (round 5: tn_arr[b] first was a dependent load in a kernel that is nothing but its latency chain)
+    const bool skipped = win_ratio[(size_t)b * K] < -0.5f;
     if (hint) {
         float r = 0.f;
         for (int vi = threadIdx.x; vi < K; vi += 64) r += win_ratio[(size_t)b * K + vi];

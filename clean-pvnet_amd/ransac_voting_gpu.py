@@ -12,6 +12,9 @@ Keyword-only additions (all default to reference behaviour):
              :145 / :235); None = counter-based RNG on the device
   selection  injected U(0,1) draws ``[b,h,w]`` float32 (the ``uniform_`` of :136 / :220)
   singular   "reference" | "zero" -- see ``ransac_voting_layer_v3``
+  out        (v3 / v1 only) a ``[b,vn,2]`` float32 CUDA tensor the keypoints are written into and that is returned --
+             e.g. this rank's rows of a persistent gather buffer (``clean_pvnet_amd.dist.GatherBuffer``), so that the
+             exchange of a sharded batch needs no copy; None = a fresh tensor
   seed, first_image   key of the device RNG (used where nothing is injected): ``seed`` defaults to a draw from torch's
              CPU generator; the generator is keyed by ``(seed, first_image + b)``, so the shards of a batch -- one per
              GPU, ``first_image`` = index of the shard's first image -- draw exactly what one call on the whole batch
@@ -54,25 +57,29 @@ def _chunks(b):
 
 
 def _vote_v3(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, idxs, selection, policy, seed=None,
-             first_image=0):
+             first_image=0, out=None):
     b = vertex.shape[0]
     if b == 0:                      # an empty shard (dist.sharded_vote on a trailing rank): nothing to launch
-        return vertex.new_zeros((0, vertex.shape[3], 2))
+        return vertex.new_zeros((0, vertex.shape[3], 2)) if out is None else out
+    if out is not None and tuple(out.shape) != (b, vertex.shape[3], 2):
+        raise ValueError("out must be [b,vn,2] = %r, got %r" % ((b, vertex.shape[3], 2), tuple(out.shape)))
     mask = _as_mask(mask, False)
     outs = []
     seed = _next_seed() if seed is None else int(seed)   # one key for the whole batch; the device RNG is keyed by (seed, image index), so the
     for lo, hi in _chunks(b):   # split below is invisible in the results
-        out, _win, _tn, _ws = _ext.ransac_voting_v3(
+        o, _win, _tn, _ws = _ext.ransac_voting_v3(
             mask[lo:hi], vertex[lo:hi], int(round_hyp_num), float(inlier_thresh), int(min_num), int(max_num),
             None if idxs is None else idxs[lo:hi], None if selection is None else selection[lo:hi],
-            seed, policy, int(first_image) + lo)
-        outs.append(out)
+            seed, policy, int(first_image) + lo, out=None if out is None else out[lo:hi])
+        outs.append(o)
+    if out is not None:
+        return out
     return outs[0] if len(outs) == 1 else torch.cat(outs)
 
 
 def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
                            min_num=5, max_num=30000, *, idxs=None, selection=None, singular="reference", seed=None,
-                           first_image=0):
+                           first_image=0, out=None):
     '''
     :param mask:      [b,h,w]
     :param vertex:    [b,h,w,vn,2]
@@ -93,11 +100,11 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     '''
     del confidence, max_iter
     return _vote_v3(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, idxs, selection,
-                    _POLICY[singular], seed, first_image)
+                    _POLICY[singular], seed, first_image, out)
 
 
 def ransac_voting_layer(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
-                        min_num=5, max_num=30000, *, idxs=None, selection=None, seed=None, first_image=0):
+                        min_num=5, max_num=30000, *, idxs=None, selection=None, seed=None, first_image=0, out=None):
     '''
     :param mask:      [b,h,w]
     :param vertex:    [b,h,w,vn,2]
@@ -110,7 +117,7 @@ def ransac_voting_layer(mask, vertex, round_hyp_num, inlier_thresh=0.999, confid
     '''
     del confidence, max_iter
     return _vote_v3(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, idxs, selection,
-                    _POLICY["image_zero"], seed, first_image)
+                    _POLICY["image_zero"], seed, first_image, out)
 
 
 def b_inv(b_mat):

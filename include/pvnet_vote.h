@@ -3,9 +3,12 @@
  * path as hand-written HIP kernels for gfx950 (MI355X).
  *
  * Every pointer named d_* is a DEVICE pointer (HBM) owned by the caller; the
- * library allocates nothing, synchronises nothing and launches everything on
- * the `stream` it is given (a hipStream_t passed as void*; NULL = the null
- * stream).  All entry points return 0 on success and a non-zero code on
+ * library allocates no device memory, synchronises nothing and launches
+ * everything on the `stream` it is given (a hipStream_t passed as void*;
+ * NULL = the null stream).  What it does own -- per device, created on first
+ * use: 8 KB of pinned host memory (the stage hint) and one side stream with
+ * 16 events (the deferred mask of the fused decode) -- pvv_shutdown() gives
+ * back.  All entry points return 0 on success and a non-zero code on
  * failure (PVV_E_*; > 0 values are hipError_t from a failed launch);
  * pvv_last_error() returns a thread-local human readable message.  There is
  * no CPU fallback anywhere in this library.
@@ -30,10 +33,19 @@ extern "C" {
 #define PVV_E_WORKSPACE (-2) /* workspace smaller than pvv_workspace_bytes() */
 
 /* ABI version of this header; pvv_abi_version() must return the same. */
-#define PVV_ABI_VERSION 7
+#define PVV_ABI_VERSION 8
 
 int pvv_abi_version(void);
 const char *pvv_last_error(void);
+
+/* ABI v8.  Library lifecycle: releases everything the library created behind the caller's back -- per device the pinned
+ * host array of the stage hint (see pvv_stage_hint_query) and the side stream with its events (ABI v7) -- and forgets
+ * every hint, so that the next call starts like the first one of a fresh process (it re-creates what it needs).  The
+ * side streams are synchronised first; the caller must have no pvv_* call in flight on another thread and should have
+ * synchronised the streams it launched on (a kernel still running may write its hint into the array this frees).  Call
+ * it before unloading the library or resetting the device, or between workloads to make timing independent of call
+ * history.  Returns 0, or the first hipError_t met (everything is released regardless). */
+int pvv_shutdown(void);
 
 /* ------------------------------------------------------------------------
  * Legacy extension-module surface: the four functions the reference's
@@ -108,7 +120,7 @@ typedef struct pvv_problem {
                                 of the network output, resnet18.py:93)          */
     /* ---- ABI v5 ---- */
     int32_t count_kernel;    /* PVV_COUNT_*: which inlier-count kernel runs; 0 (AUTO) unless cross-checking */
-    int32_t reserved0;       /* keep 0 */
+    int32_t flags;           /* PVV_FLAG_* bits (ABI v8; was reserved0: 0 keeps the v7 behaviour) */
     int32_t *d_draws_out;    /* optional DEVICE buffer [B,K,hn,2] i32 (NULL = off): the pixel (y*W + x) each
                                 hypothesis' index pair resolved to, -1 where none (image skipped).  Lets a test
                                 replay the device RNG's draws through the oracle; for the fused un_pnp call hn is
@@ -127,6 +139,14 @@ typedef struct pvv_problem {
                                 kernel's duration can be read as it runs inside the pipeline (bench.py's per-kernel
                                 rooflines).  A measurement aid: the records cost ~1 us each */
 } pvv_problem;
+
+/* pvv_problem.flags (ABI v8) */
+#define PVV_FLAG_DEVICE_RNG 1    /* the caller promises d_idxs = d_idxs_est = d_selection = NULL for the call this problem
+                                    describes (the device RNG draws everything).  Only then is it known BEFORE the call that
+                                    no per-pixel subsample draw is ever stored (small images subsample inside the compaction
+                                    kernel and evaluate draws on demand), and pvv_workspace_bytes() leaves the 4 B x H x W per
+                                    image of draw storage out: -27 % at 480x640, B = 64.  A call that sets the flag and
+                                    passes one of those pointers fails with PVV_E_ARG */
 
 /* pvv_problem.d_status bits */
 #define PVV_STATUS_SKIPPED 1     /* foreground_num < min_num: the image's keypoints are zeros (P:129-132 / P:211-216) */
@@ -170,6 +190,11 @@ typedef struct pvv_problem {
  * hypothesis and always count in full. */
 #define PVV_COUNT_FULL 2
 #define PVV_COUNT_STAGED 3
+/* ABI v8: PVV_COUNT_STAGED stages ransac_voting_layer_v3 only (its v6 meaning; under v7 it also staged an estimate whose
+ * counts are not an output).  The estimate counted in stages against its own bound (every hypothesis whose ratio can still
+ * come within 0.1 of the best, P:262-264) is exact but not faster than the full pass at most sizes, so it
+ * has its own value: what the tests use to cross-check that bound.  For v3 calls it behaves like PVV_COUNT_STAGED. */
+#define PVV_COUNT_STAGED_ESTIMATE 4
 
 /* b_inv (P:97-109) falls back to the identity for the WHOLE image when the
  * batched solve raises; REFERENCE reproduces that (x = ATb for every keypoint

@@ -20,7 +20,7 @@ class Problem(ctypes.Structure):
                 ("singular_policy", c_i32), ("inlier_thresh", c_f32),
                 ("mask_stride", c_i64 * 3), ("vertex_stride", c_i64 * 5), ("seed", c_u64),
                 ("seg_classes", c_i32), ("first_image", c_i32), ("seg_stride", c_i64 * 4),
-                ("count_kernel", c_i32), ("reserved0", c_i32), ("d_draws_out", vp), ("ev_count_begin", vp), ("ev_count_end", vp),
+                ("count_kernel", c_i32), ("flags", c_i32), ("d_draws_out", vp), ("ev_count_begin", vp), ("ev_count_end", vp),
                 ("d_status", vp), ("ev_marks", vp)]
 
 
@@ -56,12 +56,13 @@ def load():
         L.pvv_rerun_count_kernel.argtypes = [ctypes.POINTER(Problem), vp, sz, ctypes.c_int, vp]
         L.pvv_stream_read_probe.argtypes = [vp, sz, vp, vp]
         L.pvv_stage_hint_query.argtypes = [ctypes.POINTER(c_f32), ctypes.POINTER(c_f32), ctypes.POINTER(Problem), vp]
+        L.pvv_shutdown.argtypes = []
         _lib = L
     return _lib
 
 
 def problem(mask, vertex, hn, thresh, min_num=5, max_num=30000, policy=0, seed=0, count_kernel=0, draws_out=None,
-            first_image=0, cap=None, status=None):
+            first_image=0, cap=None, status=None, flags=0):
     L = load()
     p = Problem()
     p.B, p.H, p.W, p.K, _ = vertex.shape
@@ -70,6 +71,7 @@ def problem(mask, vertex, hn, thresh, min_num=5, max_num=30000, policy=0, seed=0
     p.min_num, p.max_num = min_num, max_num
     p.cap = L.pvv_default_cap(p.H, p.W, max_num) if cap is None else cap
     p.count_kernel = count_kernel
+    p.flags = flags
     p.first_image = first_image
     p.d_draws_out = None if draws_out is None else draws_out.data_ptr()
     p.d_status = None if status is None else status.data_ptr()

@@ -390,17 +390,21 @@ def test_run_owning_filter_launch_branches(synth, pkg, gpu, B, H, W, K, hn, fg, 
 def test_estimate_counted_in_stages_equals_the_full_pass(synth, pkg, gpu, B, H, W, K, hn, fg, outlier):
     """estimate_voting_distribution_with_mean zeroes every ratio below (max ratio - 0.1) in binary32 (P:262-264, k_covariance), so a
     count pass in stages may drop what provably falls below that window (stage_bound: L* - ceil(tn / 10) - margin).  Forced with
-    PVV_COUNT_STAGED (AUTO never takes it: it is exact but slower): covariances and PnP weights equal the full pass
-    bit for bit; a call that asks for the counts themselves is always counted in full."""
+    PVV_COUNT_STAGED_ESTIMATE (ABI v8; AUTO never takes it -- exact but not faster, DESIGN.md 4 -- and PVV_COUNT_STAGED stages v3
+    only): covariances and PnP weights equal the full pass bit for bit; a call that asks for the counts themselves is always
+    counted in full."""
     from clean_pvnet_amd import ransac_voting as ext
     d = synth.make_batch(B=B, H=H, W=W, K=K, fg=fg, sigma=0.05, outlier=outlier, seed=5100 + B, device=gpu)
     m, v = d["mask"], d["vertex"]
     mean = (d["kpt_2d"] + 0.25).contiguous()
     full = ext.estimate_voting_distribution(m, v, mean, hn, 0.99, 5, 30000, None, None, 9, False, 0, ext.COUNT_FULL)
     for rep in range(2):
-        st = ext.estimate_voting_distribution(m, v, mean, hn, 0.99, 5, 30000, None, None, 9, False, 0, ext.COUNT_STAGED)
+        st = ext.estimate_voting_distribution(m, v, mean, hn, 0.99, 5, 30000, None, None, 9, False, 0, ext.COUNT_STAGED_ESTIMATE)
         assert torch.equal(st[0], full[0]) and torch.equal(st[4], full[4]) and torch.equal(st[3], full[3]), rep
+    # PVV_COUNT_STAGED is v3's alone again (ADVICE r4): the estimate under it runs -- and equals -- the full pass
+    st = ext.estimate_voting_distribution(m, v, mean, hn, 0.99, 5, 30000, None, None, 9, False, 0, ext.COUNT_STAGED)
+    assert torch.equal(st[0], full[0]) and torch.equal(st[4], full[4])
     # with the counts as an output every one of them is exact, whatever the mode
-    a = ext.estimate_voting_distribution(m, v, mean, hn, 0.99, 5, 30000, None, None, 9, True, 0, ext.COUNT_STAGED)
+    a = ext.estimate_voting_distribution(m, v, mean, hn, 0.99, 5, 30000, None, None, 9, True, 0, ext.COUNT_STAGED_ESTIMATE)
     b = ext.estimate_voting_distribution(m, v, mean, hn, 0.99, 5, 30000, None, None, 9, True, 0, ext.COUNT_FULL)
     assert torch.equal(a[2], b[2]) and torch.equal(a[0], full[0])

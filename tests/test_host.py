@@ -20,7 +20,7 @@ def test_cabi_library_exports_every_declared_symbol():
     assert {"pvv_generate_hypothesis", "pvv_voting_for_hypothesis", "pvv_generate_hypothesis_vanishing_point",
             "pvv_voting_for_hypothesis_vanishing_point", "pvv_count_inliers", "pvv_ransac_voting_v3",
             "pvv_estimate_voting_distribution", "pvv_decode_keypoint_v3", "pvv_workspace_bytes", "pvv_default_cap", "pvv_last_error",
-            "pvv_abi_version", "pvv_rerun_count_kernel"} <= set(names)
+            "pvv_abi_version", "pvv_rerun_count_kernel", "pvv_shutdown"} <= set(names)
     L = ctypes.CDLL(capi.LIBPATH)
     for n in names:
         assert hasattr(L, n), "libpvnet_vote.so does not export %s" % n
@@ -31,7 +31,7 @@ def test_cabi_library_exports_every_declared_symbol():
 
 def test_cabi_version_and_cap_and_validation():
     L = capi.load()
-    assert L.pvv_abi_version() == 7
+    assert L.pvv_abi_version() == 8
     assert L.pvv_default_cap(480, 640, 30000) == 30000 + int(8 * 30000 ** 0.5) + 64
     assert L.pvv_default_cap(128, 128, 30000) == 128 * 128
     p = capi.Problem()
@@ -49,12 +49,64 @@ def test_cabi_version_and_cap_and_validation():
     assert L.pvv_generate_hypothesis(None, None, None, None, 1, 1, 1, None) == -1
 
 
+def test_workspace_size_regression_and_the_device_rng_flag():
+    """pvv_workspace_bytes is host-only.  ABI v8: a problem that promises the device RNG (PVV_FLAG_DEVICE_RNG) and is small enough
+    to subsample inside the compaction kernel reserves no per-pixel draw storage -- 4 B x H x W per image, the largest single term
+    of the round-4 workspace (78.6 of 286 MB at B = 64); without the flag, for images too large to fuse and
+    for a max_num small enough that subsampling gets its own pass, the storage stays."""
+    L = capi.load()
+
+    def ws(B, H, W, K, hn, max_num=30000, flags=0, count_kernel=0):
+        p = capi.Problem()
+        p.B, p.H, p.W, p.K, p.hn, p.mask_elem_size, p.min_num, p.max_num = B, H, W, K, hn, 8, 5, max_num
+        p.cap = L.pvv_default_cap(H, W, max_num)
+        p.inlier_thresh, p.flags, p.count_kernel = 0.99, flags, count_kernel
+        n = L.pvv_workspace_bytes(ctypes.byref(p))
+        assert n > 0, L.pvv_last_error()
+        return n
+    draws = 64 * 150 * 2048 * 4                                       # 150 tiles of 2048 pixels per 480x640 image
+    full, lean = ws(64, 480, 640, 9, 512), ws(64, 480, 640, 9, 512, flags=1)
+    assert full - lean == draws and lean < 0.74 * full               # -27 %
+    assert lean < 215e6, lean                                         # the benchmark's call: 208 MB (round 4: 286 MB)
+    assert ws(1024, 480, 640, 9, 512, flags=1) < 3.4e9               # (round 4: 4.6 GB)
+    # 540x720 = 190 tiles > 160: subsampling keeps its own pass there, and with it the stored draws
+    assert ws(16, 540, 720, 17, 2048) == ws(16, 540, 720, 17, 2048, flags=1)
+    # the reference's default call (max_num = 100 of 307 200 pixels: nearly every image is subsampled, own pass)
+    assert ws(64, 480, 640, 9, 128, max_num=100) == ws(64, 480, 640, 9, 128, max_num=100, flags=1)
+    # a mask can never exceed max_num >= 255 * H * W: no subsampling, no draws, flag or not
+    assert ws(4, 64, 64, 4, 64, max_num=255 * 64 * 64) == ws(4, 64, 64, 4, 64, max_num=255 * 64 * 64, flags=1)
+    # unknown flag bits and the new count_kernel value
+    p = capi.Problem()
+    p.B, p.H, p.W, p.K, p.hn, p.mask_elem_size, p.cap, p.flags = 1, 64, 64, 4, 64, 8, 4096, 6
+    assert L.pvv_workspace_bytes(ctypes.byref(p)) == 0 and b"flags" in L.pvv_last_error()
+    assert ws(64, 480, 640, 9, 4096, count_kernel=4) > ws(64, 480, 640, 9, 4096, count_kernel=2)      # STAGED_ESTIMATE reserves the stage words
+    p.flags, p.count_kernel = 0, 5
+    assert L.pvv_workspace_bytes(ctypes.byref(p)) == 0 and b"count_kernel" in L.pvv_last_error()
+
+
+def test_shutdown_without_a_gpu_is_a_no_op():
+    """pvv_shutdown() on a process that never launched anything has nothing to release and says so with 0 -- also twice."""
+    L = capi.load()
+    assert L.pvv_shutdown() == 0 and L.pvv_shutdown() == 0
+
+
+def test_gather_buffer_single_process(pkg):
+    """clean_pvnet_amd.dist.GatherBuffer without a process group: `mine` is the whole buffer, gather() returns it (no collective)."""
+    from clean_pvnet_amd.dist import GatherBuffer
+    buf = GatherBuffer(5, (3, 2), "cpu")
+    assert buf.mine.shape == (5, 3, 2) and buf.mine.data_ptr() == buf.full.data_ptr()
+    buf.mine.copy_(torch.arange(30.).view(5, 3, 2))
+    assert torch.equal(buf.gather(), torch.arange(30.).view(5, 3, 2))
+    out, work = buf.gather(async_op=True)
+    assert work is None and out.data_ptr() == buf.full.data_ptr()
+
+
 def test_extension_module_surface_matches_reference(pkg):
     from clean_pvnet_amd import ransac_voting as ext
     for name in ("generate_hypothesis", "voting_for_hypothesis", "generate_hypothesis_vanishing_point",
                  "voting_for_hypothesis_vanishing_point"):                  # ransac_voting.cpp:102-107
         assert callable(getattr(ext, name))
-    assert ext.abi_version == 7
+    assert ext.abi_version == 8
     import lib.csrc.ransac_voting.ransac_voting as ref_path                  # ransac_voting_gpu.py:2
     assert ref_path.generate_hypothesis is ext.generate_hypothesis
 
