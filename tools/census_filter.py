@@ -57,7 +57,12 @@ def census(synth, cfgname, B, calls, dev):
         alive = [int(((ent <= f * span_us) & (ext > f * span_us)).sum()) for f in (0.1, 0.25, 0.5, 0.6, 0.7, 0.8, 0.9)]
         by_items = {int(k): {"blocks": int((work[:, 10] == k).sum()), "life_us_median": float(life[work[:, 10] == k].median()),
                              "exit_us_median": float(ext[work[:, 10] == k].median())} for k in work[:, 10].unique().tolist()}
-        rows.append({"alive": alive, "by_items": by_items, "entry_us_p90": float(ent.quantile(0.9)), "entry_us_median": float(ent.median()),
+        order = ext.argsort(descending=True)[:12]
+        late = [{"block": int(torch.nonzero(c[:, 15].double() == work[i, 15])[0, 0]), "exit_us": round(float(ext[i]), 1), "items": int(work[i, 10]), "chunks": int(work[i, 11]),
+                 "survivor_chunks": int(work[i, 12]), "tiles_wave0": int(work[i, 13]),
+                 "kcycles": [round(float(cyc[i, j]) / 1e3, 1) for j in range(10)]} for i in order.tolist()]
+        typical = {"chunks": float(work[:, 11].median()), "survivor_chunks": float(work[:, 12].median()), "tiles_wave0": float(work[:, 13].median())}
+        rows.append({"late": late, "typical": typical, "alive": alive, "by_items": by_items, "entry_us_p90": float(ent.quantile(0.9)), "entry_us_median": float(ent.median()),
                      "blocks_launched": int(len(c)), "blocks_with_items": int(len(work)),
                      "items": int(work[:, 10].sum()), "chunks": int(work[:, 11].sum()),
                      "survivors_per_chunk_mean": float(work[:, 12].sum() / max(1.0, work[:, 11].sum())),
@@ -76,6 +81,7 @@ def census(synth, cfgname, B, calls, dev):
     mid = rows[len(rows) // 2]
     out["working_blocks_alive_at_fraction_of_span"] = dict(zip(("0.1", "0.25", "0.5", "0.6", "0.7", "0.8", "0.9"), mid["alive"]))
     out["by_items_per_block"] = mid["by_items"]
+    out["latest_blocks"], out["typical_block"] = mid["late"], mid["typical"]
     out["entry_us_median"], out["entry_us_p90"] = round(med("entry_us_median"), 2), round(med("entry_us_p90"), 2)
     out["phases"] = {n: {"median_cycles_per_block": round(medv("median_cycles", i), 0), "mean_cycles_per_block": round(medv("mean_cycles", i), 0),
                          "share_of_working_blocks_cycles": round(medv("share", i), 4)} for i, n in enumerate(PHASES)}
