@@ -45,69 +45,58 @@ __global__ __launch_bounds__(kBlock) void k_legacy_vote(const float *__restrict_
     }
 }
 
-// K:170-229
+// K:170-229 -- the intersection of two pixel rays in homogeneous coordinates.  A ray through pixel p with direction v is the
+// line  L = (v.y, -v.x, p.y v.x - p.x v.y);  two lines meet at  M = L_a x L_b  (a point at infinity when the rays are parallel:
+// m.w = 0).  M is oriented so that it lies AHEAD of both pixels along their directions (the four sign probes below), and
+// dropped -- (0,0,0) -- when the two pixels disagree about the side.  Every product and difference is the reference's, in the
+// reference's order (bit-exactness against oracle/_ref: tests/test_ref_pin.py); only the formulation and the names are ours.
+struct Line3 { float a, b, c; };
+__device__ __forceinline__ Line3 ray_line(float2 p, float2 v) { return Line3{v.y, -v.x, p.y * v.x - p.x * v.y}; }
+
 __global__ __launch_bounds__(kBlock) void k_legacy_gen_vp(const float *__restrict__ direct,
                                                           const float *__restrict__ coords,
                                                           const int32_t *__restrict__ idxs,
                                                           float *__restrict__ hypo, int tn, int vn, int hn)
 {
-    int hvi = blockIdx.x * kBlock + threadIdx.x;
-    if (hvi >= hn * vn) return;
-    int vi = hvi % vn;
-    int id0 = idxs[hvi * 2], id1 = idxs[hvi * 2 + 1];
-    const float2 *d = (const float2 *)direct;
-    const float2 *c = (const float2 *)coords;
-    float2 d0 = d[(size_t)id0 * vn + vi], d1 = d[(size_t)id1 * vn + vi];
-    float2 c0 = c[id0], c1 = c[id1];
-    float dx0 = d0.x, dy0 = d0.y, cx0 = c0.x, cy0 = c0.y;
-    float dx1 = d1.x, dy1 = d1.y, cx1 = c1.x, cy1 = c1.y;
-
-    float lx0 = dy0, ly0 = -dx0, lz0 = cy0 * dx0 - cx0 * dy0;
-    float lx1 = dy1, ly1 = -dx1, lz1 = cy1 * dx1 - cx1 * dy1;
-
-    float x = ly0 * lz1 - lz0 * ly1;
-    float y = lz0 * lx1 - lx0 * lz1;
-    float z = lx0 * ly1 - ly0 * lx1;
-
-    float val_x0 = dx0 * (x - z * cx0);
-    float val_x1 = dx1 * (x - z * cx1);
-    float val_y0 = dy0 * (y - z * cy0);
-    float val_y1 = dy1 * (y - z * cy1);
-
-    if (val_x0 < 0 && val_x1 < 0 && val_y0 < 0 && val_y1 < 0) { z = -z; x = -x; y = -y; }
-    if (val_x0 * val_x1 < 0 || val_y0 * val_y1 < 0) { x = 0.f; y = 0.f; z = 0.f; }
-
-    hypo[hvi * 3] = x;
-    hypo[hvi * 3 + 1] = y;
-    hypo[hvi * 3 + 2] = z;
+    const int pair = blockIdx.x * kBlock + threadIdx.x;          // (hypothesis, keypoint) flattened
+    if (pair >= hn * vn) return;
+    const int vi = pair % vn;
+    const int ia = idxs[pair * 2], ib = idxs[pair * 2 + 1];
+    const float2 va = ((const float2 *)direct)[(size_t)ia * vn + vi], vb = ((const float2 *)direct)[(size_t)ib * vn + vi];
+    const float2 pa = ((const float2 *)coords)[ia], pb = ((const float2 *)coords)[ib];
+    const Line3 la = ray_line(pa, va), lb = ray_line(pb, vb);
+    float3 m = make_float3(la.b * lb.c - la.c * lb.b, la.c * lb.a - la.a * lb.c, la.a * lb.b - la.b * lb.a);   // la x lb
+    // is M ahead of pixel a / b, per axis?  v . (m.xy - m.w p), component-wise
+    const float ahead_ax = va.x * (m.x - m.z * pa.x), ahead_bx = vb.x * (m.x - m.z * pb.x);
+    const float ahead_ay = va.y * (m.y - m.z * pa.y), ahead_by = vb.y * (m.y - m.z * pb.y);
+    if (ahead_ax < 0 && ahead_bx < 0 && ahead_ay < 0 && ahead_by < 0) m = make_float3(-m.x, -m.y, -m.z);   // behind both: flip (z first in K: same values)
+    if (ahead_ax * ahead_bx < 0 || ahead_ay * ahead_by < 0) m = make_float3(0.f, 0.f, 0.f);             // the pixels disagree
+    float *out = hypo + (size_t)pair * 3;
+    out[0] = m.x; out[1] = m.y; out[2] = m.z;
 }
 
-// K:268-310
+// K:268-310 -- a pixel votes for the homogeneous point M when the ray from the pixel towards M (M.xy - M.w p) runs along its
+// direction field within the threshold, on the positive side in both axes.
 __global__ __launch_bounds__(kBlock) void k_legacy_vote_vp(const float *__restrict__ direct,
                                                            const float *__restrict__ coords,
                                                            const float *__restrict__ hypo,
                                                            uint8_t *__restrict__ inliers, int tn, int vn,
                                                            int hn, int h_per_block, float thresh)
 {
-    int ti = blockIdx.x * kBlock + threadIdx.x;
-    int vi = blockIdx.y;
-    int h0 = blockIdx.z * h_per_block;
-    int h1 = min(hn, h0 + h_per_block);
+    const int ti = blockIdx.x * kBlock + threadIdx.x;
+    const int vi = blockIdx.y;
+    const int h0 = blockIdx.z * h_per_block, h1 = min(hn, h0 + h_per_block);   // this block's slab of hypotheses
     if (ti >= tn) return;
-    float2 d = ((const float2 *)direct)[(size_t)ti * vn + vi];
-    float2 c = ((const float2 *)coords)[ti];
-    float norm1 = sqrtf(d.x * d.x + d.y * d.y);
+    const float2 v = ((const float2 *)direct)[(size_t)ti * vn + vi];
+    const float2 p = ((const float2 *)coords)[ti];
+    const float len_v = sqrtf(v.x * v.x + v.y * v.y);
     for (int hi = h0; hi < h1; ++hi) {
-        const float *h = hypo + ((size_t)hi * vn + vi) * 3;
-        float hx = h[0], hy = h[1], hz = h[2];
-        float diff_x = hx - c.x * hz;
-        float diff_y = hy - c.y * hz;
-        float norm2 = sqrtf(diff_x * diff_x + diff_y * diff_y);
-        if (lt_1e6(norm1) || lt_1e6(norm2)) continue;
-        float angle_dist = (d.x * diff_x + d.y * diff_y) / (norm1 * norm2);
-        float val_x = diff_x * d.x;
-        float val_y = diff_y * d.y;
-        if (val_x < 0 || val_y < 0) continue;
-        if (fabsf(angle_dist) > thresh) inliers[((size_t)hi * vn + vi) * tn + ti] = 1;
+        const float *mp = hypo + ((size_t)hi * vn + vi) * 3;
+        const float2 to_m = make_float2(mp[0] - p.x * mp[2], mp[1] - p.y * mp[2]);
+        const float len_m = sqrtf(to_m.x * to_m.x + to_m.y * to_m.y);
+        if (lt_1e6(len_v) || lt_1e6(len_m)) continue;
+        const float cosine = (v.x * to_m.x + v.y * to_m.y) / (len_v * len_m);
+        if (to_m.x * v.x < 0 || to_m.y * v.y < 0) continue;
+        if (fabsf(cosine) > thresh) inliers[((size_t)hi * vn + vi) * tn + ti] = 1;
     }
 }

@@ -71,8 +71,12 @@ class GatherBuffer:
     every step; in a one-rank group the in-place collective is no device work at all.  With more than one step in flight the
     caller needs as many buffers as it keeps results alive (the bench rotates two)."""
 
-    def __init__(self, batch, row_shape, device, dtype=torch.float32, group=None):
-        self.batch, self.group = int(batch), group
+    def __init__(self, batch, row_shape, device, dtype=torch.float32, group=None, comm=None):
+        """``comm``: a ``clean_pvnet_amd.rccl.Comm`` (or None).  With it ``gather()`` issues RCCL's all-gather directly on the
+        CURRENT stream -- behind the voting kernels in stream order, no event, no second stream (rccl.py) -- instead of going
+        through ``torch.distributed`` (float32 buffers only)."""
+        self.batch, self.group, self.comm = int(batch), group, comm
+        assert comm is None or dtype == torch.float32
         live = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if live else 1
         self.rank = dist.get_rank(group) if live else 0
@@ -87,6 +91,9 @@ class GatherBuffer:
         out = self.full[: self.batch]
         if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             return (out, None) if async_op else out
+        if self.comm is not None:
+            self.comm.all_gather_f32(self.send, self.full)
+            return (out, _Done()) if async_op else out
         if self.full.is_cuda and dist.get_backend(self.group) == "gloo":
             # ranks sharing a GPU (the two-ranks-on-one-GPU tests): gloo moves host memory, stage the few bytes through it
             host = self.send.cpu()

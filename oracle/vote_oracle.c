@@ -290,6 +290,41 @@ ORC_API void orc_v3_image(const float *direct, const float *coords,
     }
 }
 
+/* ransac_voting_gpu.py:125-144 for ONE image in C (bench.py's cpu_baseline leg: round 4 did this step in single-threaded numpy inside
+ * the timed loop; the readable numpy restatement, vote_oracle.py compact_v3, stays what the parity tests use, and tests/test_oracle.py
+ * checks the two against each other).  mask: [H,W] of `es`-byte little-endian integers, `mask.byte()` = the low byte (:125);
+ * foreground_num = the SUM of the bytes (:126); if it exceeds max_num a pixel survives iff selection[p] < fl32(max_num / foreground_num)
+ * (:135-138; `selection` = the injected U(0,1) draws, required then).  Writes coords [tn,2] = (x,y) (:140-141) and direct [tn,vn,2]
+ * (:142-143) in row-major pixel order -- at most cap_rows rows -- and returns foreground_num; *tn_out = rows written, or -1 when
+ * subsampling was needed and no selection was given. */
+ORC_API long long orc_compact_v3(const void *mask, int es, const float *vertex, int H, int W, int vn, const float *selection,
+                                 int max_num, float *coords, float *direct, int cap_rows, int *tn_out)
+{
+    const uint8_t *mb = (const uint8_t *)mask;
+    const long long HW = (long long)H * W;
+    long long fg = 0;
+    for (long long p = 0; p < HW; ++p) fg += mb[p * es];
+    int sub = fg > (long long)max_num;
+    float prob = 2.f;
+    if (sub) {
+        if (!selection) { *tn_out = -1; return fg; }
+        prob = (float)max_num / (float)fg;
+    }
+    int tn = 0;
+    for (int y = 0; y < H && tn < cap_rows; ++y)
+        for (int x = 0; x < W && tn < cap_rows; ++x) {
+            const long long p = (long long)y * W + x;
+            if (!mb[p * es]) continue;
+            if (sub && !(selection[p] < prob)) continue;
+            coords[tn * 2] = (float)x;
+            coords[tn * 2 + 1] = (float)y;
+            memcpy(direct + (size_t)tn * vn * 2, vertex + (size_t)p * vn * 2, sizeof(float) * 2 * (size_t)vn);
+            ++tn;
+        }
+    *tn_out = tn;
+    return fg;
+}
+
 /* ransac_voting_gpu.py:231-269 for ONE compacted image.               */
 /* idxs [hn_total,vn,2] holds the `round_num` rounds concatenated      */
 /* (:235,249), `foreground` is tn as float (:244).                     */

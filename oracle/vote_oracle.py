@@ -212,6 +212,31 @@ def compact_estimate(mask2d, vertex_hwk2, max_num=30000, selection=None):
     return fg0, coords, direct
 
 
+def compact_v3_c(mask2d, vertex_hwk2, max_num=30000, selection=None):
+    """``compact_v3`` in C (``orc_compact_v3``): the same ``(fg_sum, coords, direct)``, no numpy pass over the image --
+    what bench.py's cpu_baseline leg times.  tests/test_oracle.py checks it against the numpy restatement above."""
+    m = np.ascontiguousarray(mask2d)
+    if m.dtype == np.bool_:
+        m = m.view(np.uint8)
+    assert m.dtype.kind in "iu", m.dtype
+    v = _c(vertex_hwk2, np.float32)
+    H, W, vn, _ = v.shape
+    sel = None if selection is None else _c(selection, np.float32)
+    rows = int(np.count_nonzero(m)) if sel is not None else H * W
+    rows = min(H * W, max(1, rows))
+    # (row capacity: every pixel of the image at most; the count above is only taken when draws are injected)
+    coords = np.empty((H * W if sel is None else rows, 2), np.float32)
+    direct = np.empty((coords.shape[0], vn, 2), np.float32)
+    tn = ctypes.c_int(0)
+    f = lib().orc_compact_v3
+    f.restype = ctypes.c_longlong
+    fg = f(m.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(m.dtype.itemsize), _p(v, _f32p), H, W, vn,
+           None if sel is None else _p(sel, _f32p), int(max_num), _p(coords, _f32p), _p(direct, _f32p), coords.shape[0],
+           ctypes.byref(tn))
+    assert tn.value >= 0, "subsampling active: inject `selection`"
+    return int(fg), coords[: tn.value], direct[: tn.value]
+
+
 def v3_image(direct, coords, idxs, thresh):
     """Select + refit of one compacted image (C oracle). Returns a dict of everything."""
     direct, coords, idxs = _c(direct, np.float32), _c(coords, np.float32), _c(idxs, np.int32)
@@ -233,7 +258,7 @@ def v3_image(direct, coords, idxs, thresh):
 
 def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99,
                            max_iter=20, min_num=5, max_num=30000, *, idxs, selection=None,
-                           singular="reference", details=None):
+                           singular="reference", details=None, compact_in_c=False):
     """ransac_voting_gpu.py:112-199 on numpy arrays.
 
     ``idxs``: per-image injected index pairs, ``[B,hn,vn,2]`` (entries for skipped
@@ -251,8 +276,8 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     b, h, w, vn, _ = vertex.shape
     out = np.zeros((b, vn, 2), np.float32)
     for bi in range(b):
-        fg, coords, direct = compact_v3(mask[bi], vertex[bi], max_num,
-                                        None if selection is None else selection[bi])
+        fg, coords, direct = (compact_v3_c if compact_in_c else compact_v3)(mask[bi], vertex[bi], max_num,
+                                                                            None if selection is None else selection[bi])
         if fg < min_num:                                               # :129-132
             if details is not None:
                 details.append(dict(tn=0, skipped=True))

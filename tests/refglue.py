@@ -34,26 +34,71 @@ GLUE_PYC = os.path.join(REF_DIR, "ref_ransac_voting_gpu.pyc")
 RESNET_PYC = os.path.join(REF_DIR, "ref_resnet18.pyc")
 
 
+def _pyc_matches_this_python(path):
+    """byte code is bound to the interpreter's minor version: its first four bytes are importlib.util.MAGIC_NUMBER"""
+    try:
+        with open(path, "rb") as f:
+            return f.read(4) == importlib.util.MAGIC_NUMBER
+    except OSError:
+        return False
+
+
 def available():
-    return os.path.exists(GLUE_PYC) and os.path.exists(RESNET_PYC)
+    """Both .pyc files exist AND were compiled by this Python's minor version (a mismatch used to surface as an
+    ImportError inside the tests instead of a skip)."""
+    return _pyc_matches_this_python(GLUE_PYC) and _pyc_matches_this_python(RESNET_PYC)
 
 
-def _torch11_shims():
-    if getattr(torch, "_pvv_torch11_shims", False):
+_shim_state = {"depth": 0, "saved": None}
+
+
+def install_torch11_shims():
+    """torch.solve with torch-1.1 semantics and masked_select with a uint8 mask -- what the reference's glue calls at RUN time.
+    Nested installs are counted; ``remove_torch11_shims`` restores the originals when the last one leaves (the
+    patches used to stay for the whole pytest session and every later test ran against a patched torch).  The test modules
+    that run the reference's code hold them through the module-scoped ``torch11`` fixture below."""
+    if _shim_state["depth"] == 0:
+        missing = object()
+        _shim_state["saved"] = (getattr(torch, "solve", missing), torch.Tensor.masked_select, missing)
+
+        def solve(B, A):                           # torch 1.1: torch.solve(B, A) -> (X, LU), raises on a singular A
+            X, info = torch.linalg.solve_ex(A, B)
+            if (info != 0).any() or not torch.isfinite(X).all():
+                raise RuntimeError("solve: U(i,i) is zero, singular U.")
+            return X, None
+        torch.solve = solve
+        orig = torch.Tensor.masked_select
+
+        def masked_select(self, mask):
+            return orig(self, mask.bool() if mask.dtype == torch.uint8 else mask)
+        torch.Tensor.masked_select = masked_select
+    _shim_state["depth"] += 1
+
+
+def remove_torch11_shims():
+    if _shim_state["depth"] == 0:
         return
+    _shim_state["depth"] -= 1
+    if _shim_state["depth"] == 0:
+        solve0, ms0, missing = _shim_state["saved"]
+        if solve0 is missing:
+            del torch.solve
+        else:
+            torch.solve = solve0
+        torch.Tensor.masked_select = ms0
+        _shim_state["saved"] = None
 
-    def solve(B, A):                           # torch 1.1: torch.solve(B, A) -> (X, LU), raises on a singular A
-        X, info = torch.linalg.solve_ex(A, B)
-        if (info != 0).any() or not torch.isfinite(X).all():
-            raise RuntimeError("solve: U(i,i) is zero, singular U.")
-        return X, None
-    torch.solve = solve
-    orig = torch.Tensor.masked_select
 
-    def masked_select(self, mask):
-        return orig(self, mask.bool() if mask.dtype == torch.uint8 else mask)
-    torch.Tensor.masked_select = masked_select
-    torch._pvv_torch11_shims = True
+def torch11_fixture():
+    """-> a module-scoped autouse pytest fixture: shims installed for the module's tests, originals restored behind them."""
+    import pytest
+
+    @pytest.fixture(scope="module", autouse=True)
+    def torch11():
+        install_torch11_shims()
+        yield
+        remove_torch11_shims()
+    return torch11
 
 
 def _load_pyc(name, path, package=None):
@@ -120,7 +165,7 @@ def load_glue(extension=None):
     i.e. the product's HIP module).  The module global ``ransac_voting`` may be replaced afterwards (``Draws``)."""
     if not os.path.exists(GLUE_PYC):
         raise FileNotFoundError("%s is missing: run `make -C oracle _ref_py` where /root/reference exists" % GLUE_PYC)
-    _torch11_shims()
+    assert _shim_state["depth"] > 0, "hold the torch-1.1 shims while the reference's code runs (refglue.torch11_fixture / install_torch11_shims)"
     if extension is None:
         import lib.csrc.ransac_voting.ransac_voting as extension   # noqa: F811  (this repository's shim -> the HIP module)
         mod = _load_pyc("ref_ransac_voting_gpu", GLUE_PYC)
@@ -150,7 +195,7 @@ def load_resnet18(un_pnp):
     """The reference's lib/networks/pvnet/resnet18.py; returns (module, cfg).  ``cfg.test.un_pnp`` is a live attribute."""
     if not os.path.exists(RESNET_PYC):
         raise FileNotFoundError("%s is missing: run `make -C oracle _ref_py` where /root/reference exists" % RESNET_PYC)
-    _torch11_shims()
+    assert _shim_state["depth"] > 0, "hold the torch-1.1 shims while the reference's code runs (refglue.torch11_fixture / install_torch11_shims)"
     import lib                                                   # this repository's lib/ (csrc only)
     cfg = types.SimpleNamespace(test=types.SimpleNamespace(un_pnp=bool(un_pnp)))
     stubs = {}

@@ -62,6 +62,24 @@ def _worker(rank, world, port, batch, q):
         cov2, work = pdist.gather_results(cov_local, batch, async_op=True)
         work.wait()
         assert torch.equal(cov2, cov)
+        # GatherBuffer (round 5): the persistent buffer the voting call writes into (out=buf.mine), ONE in-place collective -- the
+        # same rows in the same order, uneven and empty shards included, and reusable step after step
+        buf = pdist.GatherBuffer(batch, (cfg["K"], 2, 2), "cpu")
+        assert buf.mine.shape[0] == hi - lo and (buf.lo, buf.hi) == (lo, hi)
+        for rep in range(2):
+            buf.mine.copy_(cov_local + rep)
+            got = buf.gather()
+            assert got.shape == cov.shape and got.data_ptr() == buf.full.data_ptr()
+            # (rows of rank r carry 1000 r + rep: compare with the padded-gather result shifted by rep)
+            assert torch.equal(got, cov + rep), rep
+        g2, w2 = buf.gather(async_op=True)
+        w2.wait()
+        assert torch.equal(g2, cov + 1)
+        # out= through the layer: the vote function receives the buffer's rows and fills them
+        kbuf = pdist.GatherBuffer(batch, (cfg["K"], 2), "cpu")
+        if d is not None:
+            kbuf.mine.copy_(vote(m, v, cfg["hn"]))
+        assert torch.equal(kbuf.gather(), out)
         q.put((rank, out.numpy(), cov.numpy()))
     finally:
         dist.destroy_process_group()

@@ -27,11 +27,14 @@ def test_bench_under_torchrun_one_rank_executes_the_rccl_exchange(gpu):
     r = subprocess.run(cmd, capture_output=True, text=True, env=_env(), timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["scaling"] == "weak"
-    assert line["extra"]["rccl_ranks"] == 1 and "all_gather_into_tensor" in line["extra"]["exchange"]
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["scaling"] == "strong"           # (BASELINE config 3 read literally: the default since round 5)
+    assert line["value_strong"] == line["value"] == line["value_weak"]                          # one GPU: the two modes are the same run
+    assert line["extra"]["rccl_ranks"] == 1 and "all_gather" in line["extra"]["exchange"]
     assert line["config"]["global_batch"] == 4 and line["config"]["batch_per_gpu"] == 4
     assert line["value"] > 0 and line["extra"]["known_answer_max_err_px"] < 20
-    assert len(line["extra"]["per_rank_count_kernel_ms"]) == 1 and line["roofline_contract_count_pass"]["kernel_ms_avg"] > 0 and 0 < line["roofline"]["frac"]
+    assert len(line["extra"]["per_rank_count_kernel_ms"]) == 1 and line["roofline_contract_count_pass"]["kernel_ms_avg"] > 0
+    assert line["roofline"]["bound"] == "valu_issue" and 0 < line["roofline_dense_equivalent"]["frac"]
+    assert "in-place" in line["extra"]["exchange"] and line["extra"]["exchange_impl"].startswith("rccl")
 
 
 _SHARDED = r"""
@@ -57,10 +60,31 @@ both = pdist.gather_results(torch.cat([a, b]), 5)
 empty = pdist.sharded_vote(ransac_voting_layer_v3, d["mask"][:0], d["vertex"][:0], 0, c["hn"], inlier_thresh=0.99, seed=1)
 mean, cov = estimate_voting_distribution_with_mean(d["mask"], d["vertex"], want, seed=7)
 cov_g = pdist.gather_results(cov, 5)
+# round 5: RCCL's all-gather issued directly on the launch stream (clean_pvnet_amd/rccl.py), through the persistent gather buffer
+from clean_pvnet_amd import rccl
+comm = rccl.Comm.create(dev)
+direct = dict(created=comm is not None, error=rccl.Comm.last_error)
+if comm is not None:
+    buf = pdist.GatherBuffer(5, (4, 2), dev, comm=comm)
+    for rep in range(3):                                  # the buffer is reused step after step
+        ransac_voting_layer_v3(d["mask"], d["vertex"], c["hn"], inlier_thresh=0.99, seed=4242, out=buf.mine)
+        g = buf.gather()
+    send = torch.arange(12., device=dev)
+    recv = torch.zeros(12, device=dev)
+    comm.all_gather_f32(send, recv)                       # not in place: one rank -> a copy
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                         # and on another stream: the current one is taken
+        recv2 = torch.zeros(12, device=dev)
+        comm.all_gather_f32(send, recv2)
+    side.synchronize()
+    torch.cuda.synchronize()
+    direct.update(equal=bool(torch.equal(g, want)), copy=bool(torch.equal(recv, send)), copy2=bool(torch.equal(recv2, send)),
+                  in_place=g.data_ptr() == buf.full.data_ptr())
+    comm.destroy()
 torch.cuda.synchronize()
 print(json.dumps(dict(equal=bool(torch.equal(got, want)), split_equal=bool(torch.equal(both, want)), shape=list(got.shape),
                       empty=list(empty.shape), cov_equal=bool(torch.equal(cov_g, cov)), backend=dist.get_backend(),
-                      err=float((got - d["kpt_2d"]).abs().max()))))
+                      err=float((got - d["kpt_2d"]).abs().max()), direct=direct)))
 dist.destroy_process_group()
 """ % ROOT
 
@@ -75,6 +99,9 @@ def test_hip_layer_under_a_one_rank_nccl_group_equals_the_unsharded_call(gpu):
     assert res["backend"] == "nccl"
     assert res["equal"] and res["split_equal"] and res["cov_equal"]
     assert res["shape"] == [5, 4, 2] and res["empty"] == [0, 4, 2] and res["err"] < 10
+    dr = res["direct"]                                            # the ctypes RCCL communicator on a one-rank group
+    assert dr["created"], dr
+    assert dr["equal"] and dr["copy"] and dr["copy2"] and dr["in_place"]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -138,13 +165,13 @@ def test_hip_layer_in_a_world_of_two_ranks_on_one_gpu_uneven_shards(gpu, tmp_pat
 def test_bare_bench_gpus_2_launches_its_own_ranks(gpu):
     """`python bench.py --gpus 2 --steps 3` with NO launcher and no WORLD_SIZE (it used to die on an
     assertion): bench.py starts its ranks under torch.distributed.run itself.  On this 1-GPU box the two ranks share the
-    device and exchange over gloo; --scaling strong cuts the 5 images into shards of 3 + 2; the weak-scaling (5 per rank)
+    device and exchange over gloo; strong scaling (the default) cuts the 5 images into shards of 3 + 2; the weak-scaling (5 per rank)
     and overlapped-exchange legs are included."""
     env = _env()
     for k in ("WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "5",
-           "--rotate", "2", "--prewarm-ms", "20", "--scaling", "strong"]
+           "--rotate", "2", "--prewarm-ms", "20"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -156,4 +183,5 @@ def test_bare_bench_gpus_2_launches_its_own_ranks(gpu):
     assert ex["oversubscribed_ranks_per_gpu"] == 2 and ex["rccl_ranks"] is None
     assert len(ex["per_rank_count_kernel_ms"]) == 2 and all(x > 0 for x in ex["per_rank_count_kernel_ms"])
     assert ex["known_answer_max_err_px"] < 20 and ex["weak_scaling_images_per_s"] > 0
+    assert line["value_strong"] == line["value"] and line["value_weak"] == ex["weak_scaling_images_per_s"]
     assert "scaling_vs_n1_profile" in ex and line["cpu_baseline"] is None

@@ -27,6 +27,7 @@ from tests import tolerances as tol
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+torch11 = refglue.torch11_fixture()        # the torch-1.1 shims the reference's code needs: held for this module only, then restored
 
 
 def _np(t):
@@ -34,7 +35,7 @@ def _np(t):
 
 
 @pytest.fixture(scope="module")
-def ref(pkg, gpu):
+def ref(pkg, gpu, torch11):
     # fails (not skips) when the byte code did not travel: this test IS the drop-in claim
     return refglue.load_glue()
 

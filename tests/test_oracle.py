@@ -241,3 +241,31 @@ def test_argmax_takes_first_maximum(oracle):
     # the degenerate (0,0) hypothesis is still voted on like any other (A.1): pixel (10,10) looks straight at it
     assert (r["hypo_pts"][2, 0] == 0).all()
     assert r["counts"][:, 0].tolist() == [4, 4, 1] and r["win_idx"][0] == 0
+
+
+def test_c_compaction_equals_the_numpy_restatement(oracle):
+    """orc_compact_v3 (what bench.py's cpu_baseline leg times since round 5: no numpy in the timed loop) against compact_v3, the
+    readable restatement of ransac_voting_gpu.py:125-144 the parity tests use: int64 / uint8 / bool masks, byte values above 1
+    (foreground_num sums the BYTES, :126), int64 values whose low byte is 0, and the subsample of :135-138 with injected draws."""
+    rng = np.random.RandomState(7)
+    H, W, K = 37, 53, 3
+    v = rng.randn(H, W, K, 2).astype(np.float32)
+    base = (rng.rand(H, W) < 0.3)
+    for m in (base.astype(np.int64), base.astype(np.uint8), base, base.astype(np.int64) * 3, base.astype(np.int64) * 256,
+              base.astype(np.int32) * 255, np.zeros((H, W), np.int64)):
+        a, b = oracle.compact_v3(m, v, 10 ** 9), oracle.compact_v3_c(m, v, 10 ** 9)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), m.dtype
+    sel = rng.rand(H, W).astype(np.float32)
+    a, b = oracle.compact_v3(base.astype(np.int32) * 255, v, 30000, sel), oracle.compact_v3_c(base.astype(np.int32) * 255, v, 30000, sel)
+    assert a[0] == b[0] == 255 * int(base.sum()) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])   # bytes of 255: subsampled
+    for mx in (50, 200, 10 ** 6):
+        m = base.astype(np.int64)
+        a, b = oracle.compact_v3(m, v, mx, sel), oracle.compact_v3_c(m, v, mx, sel)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), mx
+    # and the layer on top of either compaction gives the same keypoints
+    m = base.astype(np.int64)[None]
+    tn = int(base.sum())
+    idxs = rng.randint(0, tn, (1, 32, K, 2)).astype(np.int32)
+    o1 = oracle.ransac_voting_layer_v3(m, v[None], 32, 0.99, idxs=idxs)
+    o2 = oracle.ransac_voting_layer_v3(m, v[None], 32, 0.99, idxs=idxs, compact_in_c=True)
+    assert np.array_equal(o1, o2)

@@ -12,6 +12,7 @@ import torch
 from tests import refglue
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+torch11 = refglue.torch11_fixture()        # the torch-1.1 shims the reference's code needs: held for this module only, then restored
 needs_pyc = pytest.mark.skipif(not refglue.available(), reason="oracle/_ref/*.pyc not built (make -C oracle _ref_py needs /root/reference)")
 
 
@@ -54,3 +55,19 @@ def test_reference_resnet18_bytecode_loads_with_stubbed_config_and_backbone():
     assert mod.ransac_voting_layer_v3 is drop_in.ransac_voting_layer_v3
     assert mod.estimate_voting_distribution_with_mean is drop_in.estimate_voting_distribution_with_mean
     assert mod.cfg is cfg
+
+
+def test_torch11_shims_are_restored_behind_the_modules_that_need_them():
+    """the shims used to stay patched into torch for the rest of the session.  Inside this module they are held by the
+    module fixture; a nested install / remove pair leaves them in place, and the pyc check refuses byte code of another Python."""
+    assert refglue._shim_state["depth"] >= 1 and hasattr(torch, "solve")
+    before = torch.Tensor.masked_select
+    refglue.install_torch11_shims()
+    refglue.remove_torch11_shims()
+    assert torch.Tensor.masked_select is before and refglue._shim_state["depth"] >= 1
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".pyc") as f:
+        f.write(b"\x00\x00\x00\x00rest")
+        f.flush()
+        assert not refglue._pyc_matches_this_python(f.name)
+    assert not refglue._pyc_matches_this_python("/nonexistent.pyc")
