@@ -21,7 +21,7 @@ CONFIGS = {
 }
 
 
-def _image(i, H, W, K, fg, sigma, outlier, occlude, seed, device, mask_dtype):
+def _image(i, H, W, K, fg, sigma, outlier, occlude, seed, device, mask_dtype, wrong_region=0.0, kp_outlier=None):
     g = torch.Generator(device="cpu").manual_seed(seed + i)
     u = lambda lo, hi: lo + (hi - lo) * torch.rand((), generator=g).item()  # noqa: E731
     frac = u(*fg) if isinstance(fg, (tuple, list)) else fg
@@ -58,20 +58,41 @@ def _image(i, H, W, K, fg, sigma, outlier, occlude, seed, device, mask_dtype):
         rnd = torch.stack([torch.cos(ang), torch.sin(ang)], -1)
         sel = torch.rand((H, W, 1, 1), generator=dg, device=device) < out_frac
         v = torch.where(sel, rnd, v)
+    # STRUCTURED errors (round 5: what AUTO's stage decision is tested against besides uniform random outliers):
+    #  wrong_region  a contiguous slab of the object (one end of the ellipse, ~this fraction of its extent along the major axis)
+    #                whose field votes, consistently, for a WRONG point per keypoint -- a decoy 0.5-1.5 object sizes away;
+    #  kp_outlier    (lo, hi): every keypoint gets its own fraction of random-direction pixels, uniform in [lo, hi] -- the winners'
+    #                inlier ratios then spread over keypoints within one image instead of sitting at one value.
+    if wrong_region and wrong_region > 0:
+        slab = xr > a * (1.0 - 2.0 * float(wrong_region))
+        ang_d = torch.tensor([u(0.0, 2 * math.pi) for _ in range(K)], device=device)
+        rad_d = torch.tensor([u(0.5, 1.5) * max(a, b) for _ in range(K)], device=device)
+        dkx, dky = kx + rad_d * torch.cos(ang_d), ky + rad_d * torch.sin(ang_d)
+        wx = dkx.view(1, 1, K) - xs.view(1, W, 1)
+        wy = dky.view(1, 1, K) - ys.view(H, 1, 1)
+        wn = torch.sqrt(wx * wx + wy * wy).clamp(min=1e-3)
+        vw = torch.stack([wx / wn, wy / wn], -1) + sigma * torch.randn(v.shape, generator=dg, device=device)
+        v = torch.where(slab.view(H, W, 1, 1), vw, v)
+    if kp_outlier is not None:
+        fk = torch.tensor([u(*kp_outlier) for _ in range(K)], device=device)
+        ang = 2 * math.pi * torch.rand((H, W, K), generator=dg, device=device)
+        rnd = torch.stack([torch.cos(ang), torch.sin(ang)], -1)
+        sel = torch.rand((H, W, K), generator=dg, device=device) < fk.view(1, 1, K)
+        v = torch.where(sel.unsqueeze(-1), rnd, v)
     bg = 2 * torch.rand(v.shape, generator=dg, device=device) - 1
     v = torch.where(m.view(H, W, 1, 1), v, bg)
     return m.to(mask_dtype), v.float(), torch.stack([kx, ky], -1)
 
 
 def make_batch(B, H, W, K, fg=0.02, sigma=0.05, outlier=0.0, occlude=False, seed=1234, first_index=0,
-               device="cpu", mask_dtype=torch.int64, planar=False, **_unused):
+               device="cpu", mask_dtype=torch.int64, planar=False, wrong_region=0.0, kp_outlier=None, **_unused):
     """-> dict(mask [B,H,W], vertex [B,H,W,K,2] float32, kpt_2d [B,K,2]).
 
     ``planar=True`` returns the vertex as the strided view ``decode_keypoint`` produces
     (resnet18.py:66-68): storage ``[B,2K,H,W]``, ``permute(0,2,3,1).view(B,H,W,K,2)``."""
     masks, verts, kpts = [], [], []
     for i in range(B):
-        m, v, k = _image(first_index + i, H, W, K, fg, sigma, outlier, occlude, seed, device, mask_dtype)
+        m, v, k = _image(first_index + i, H, W, K, fg, sigma, outlier, occlude, seed, device, mask_dtype, wrong_region, kp_outlier)
         masks.append(m); verts.append(v); kpts.append(k)
     mask = torch.stack(masks)
     vertex = torch.stack(verts)
