@@ -24,4 +24,9 @@ python tools/staged_ab.py --cases cfg3:8,cfg3:16,cfg3:32,cfg3:64,cfg4:32,cfg5:16
 rm -f $OUT/staged_ab_outliers.jsonl
 for o in 0.03 0.05 0.095 0.2 0.3; do python tools/staged_ab.py --cases cfg3:16,cfg3:32,cfg3:64,cfg3:128,cfg5:16 --outlier $o --rotate 2 >> $OUT/staged_ab_outliers.jsonl 2>> $OUT/staged_ab.log; done
 python -c "import json,sys; json.dump([json.loads(l) for l in open(sys.argv[1]) if l.startswith('{')], open(sys.argv[2],'w'), indent=1)" $OUT/staged_ab_outliers.jsonl $OUT/staged_ab_outliers.json
+# round 5: AUTO's regret on structured errors; the phase census of the filter kernel (needs build/variants/stamps.so: tools/build_variant.sh
+# stamps -DPVV_TUNING -DPVV_STAMPS, built before the call); the per-tile loop microbenchmark
+python tools/auto_regret.py --out $OUT/auto_regret.json > $OUT/auto_regret.log 2>&1
+if [ -f build/variants/stamps.so ]; then PVV_LIBPATH=build/variants/stamps.so python tools/census_filter.py --cases cfg3:64,cfg5:16 --out $OUT/filter_census.json > $OUT/census.log 2>&1; fi
+if [ -x build/mb/cp2 ]; then build/mb/cp2 > $OUT/count_pipe2.txt 2>&1; fi
 tail -3 $OUT/profile.log; tail -c 600 $OUT/bench_default.json; grep -c "" $OUT/configs.log

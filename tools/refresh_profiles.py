@@ -102,6 +102,7 @@ def kernel_block(summary, kern):
         return summary["pmc"].get(kern, {}).get(name, {}).get("main_mean", 0.0)
     fmul = 2.0 if kern in WIDE_STREAMS else 1.0
     gui, act = v("GRBM_GUI_ACTIVE"), v("SQ_ACTIVE_INST_VALU")
+    mfma, mfma_cyc = v("SQ_INSTS_MFMA"), v("SQ_VALU_MFMA_BUSY_CYCLES")
     blk = {"FETCH_SIZE_KB": v("FETCH_SIZE"), "WRITE_SIZE_KB": v("WRITE_SIZE"), "fetch_correction": fmul,
            "hbm_bytes": int((fmul * v("FETCH_SIZE") + v("WRITE_SIZE")) * 1024),
            "SQ_INSTS_VALU": int(v("SQ_INSTS_VALU")), "SQ_ACTIVE_INST_VALU": int(act), "GRBM_GUI_ACTIVE": int(gui),
@@ -109,6 +110,11 @@ def kernel_block(summary, kern):
            "valu_busy": round(min(1.0, act * 4 / 1024 / (gui / 8)), 4) if gui else None,
            "valu_busy_raw": round(act * 4 / 1024 / (gui / 8), 4) if gui else None,
            "avg_us": summary.get("kernel_stats", {}).get(kern, {}).get("avg_us")}
+    if mfma:      # round 5: the matrix pipe (SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles per v_mfma_f32_32x32x16_bf16, summed over the SIMDs)
+        blk.update({"SQ_INSTS_MFMA": int(mfma), "SQ_VALU_MFMA_BUSY_CYCLES": int(mfma_cyc),
+                    "mfma_busy": round(mfma_cyc / 1024 / (gui / 8), 4) if gui else None,
+                    "valu_per_mfma": round(v("SQ_INSTS_VALU") / mfma, 2), "SQ_INSTS_LDS": int(v("SQ_INSTS_LDS")),
+                    "SQ_LDS_BANK_CONFLICT": int(v("SQ_LDS_BANK_CONFLICT"))})
     if kern in WIDE_STREAMS:
         blk["fetch_correction_why"] = WIDE_STREAMS[kern]
     return blk
@@ -118,7 +124,8 @@ call = {"workload": old.get("workload"), "round": TAG,
         "command": "python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-two-stream --no-side-legs",
         "how": "separate rocprofv3 --pmc passes of that command (tools/profile_bench.sh), per launch: the mean over the launches of the "
                "bench batch; hbm_bytes = (fetch_correction x FETCH_SIZE + WRITE_SIZE) x 1024; valu_busy = SQ_ACTIVE_INST_VALU x 4 / 1024 "
-               "SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); gathers and atomics are taken x1.0, uncalibrated",
+               "SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8); gathers and "
+               "atomics are taken x1.0, uncalibrated",
         "kernels": {k: kernel_block(summ, k) for k in summ["pmc"]}}
 side_path = os.path.join(fin, "prof_side_summary.json")
 if os.path.exists(side_path):
@@ -129,7 +136,7 @@ if os.path.exists(side_path):
                                      command="python tools/prof_side.py")
     call["decode_fused"] = {k: kernel_block(side, k) for k in ("k_tile_scan_seg2", "k_mask_from_lists") if k in side.get("pmc", {})}
 json.dump(call, open(os.path.join(ROOT, "profiles", "call_pmc.json"), "w"), indent=1)
-for extra_name in ("staged_ab.json", "staged_ab_outliers.json", "ab_filter_runs.txt"):
+for extra_name in ("staged_ab.json", "staged_ab_outliers.json", "ab_filter_runs.txt", "auto_regret.json", "filter_census.json", "count_pipe2.txt"):
     if os.path.exists(os.path.join(fin, extra_name)):
         import shutil
         shutil.copy(os.path.join(fin, extra_name), os.path.join(ROOT, "profiles", TAG + "_" + extra_name))
