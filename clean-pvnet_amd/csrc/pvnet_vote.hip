@@ -600,14 +600,22 @@ CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
     return a;
 }
 
-// The ESTIMATE in stages (round 4, measured and never taken by AUTO): estimate_voting_distribution_with_mean weighs every hypothesis
-// whose ratio lies within 0.1 of the best (P:262-264), so its count pass may drop what provably falls below that window
-// (stage_bound, count_bf16.hpp) when nobody asked for the counts themselves.  Covariances and PnP weights are bit-identical to the
-// full pass (tests/test_gpu_staged.py), a third of the hypothesis-tile work goes away -- and the call does not get reliably faster
-// (4096 hypotheses at 480x640, K = 9, staged vs full: 1.437 vs 1.402 ms at B = 64, 0.225 vs 0.219 at B = 8, 0.074 vs 0.054 at B = 1;
-// profiles/r04_experiments.txt): the full kernel builds a chunk's pixel operands once for all eight groups and runs VALU-saturated,
-// the second launch pays its per-chunk prologue per 512 survivors.  ABI v8: only PVV_COUNT_STAGED_ESTIMATE takes this path (the
-// tests' cross-check of the bound); PVV_COUNT_STAGED means v3 alone again.
+// The ESTIMATE in stages: estimate_voting_distribution_with_mean weighs every hypothesis whose ratio lies within 0.1 of the best
+// (P:262-264), so its count pass may drop what provably falls below that window (stage_bound, count_bf16.hpp) when nobody asked
+// for the counts themselves.  Covariances and PnP weights are bit-identical to the full pass (tests/test_gpu_staged.py); a third of
+// the hypothesis-tile work goes away.  Round 4 measured it exact and NOT faster (1.437 vs 1.402 ms at B = 64, 4096 hypotheses) and
+// kept AUTO away from it -- with a second launch that, unnoticed, ran four blocks per CU instead of five (count_filter_runs.hpp:
+// its LDS was one allocation granule too large).  With five (round 5, tools/estimate_ab.py, 480x640, K = 9, 4096 hypotheses,
+// staged vs full): 1.2385 vs 1.3992 ms at B = 64 (+13 %; +12 % with 9.5 % outlier pixels), 0.657 vs 0.709 at B = 32, 0.369 vs 0.377
+// at B = 16, 0.205 vs 0.218 at B = 8, 0.075 vs 0.053 at B = 1; 540x720, K = 17, 2048 hypotheses at B = 16: 1.438 vs 1.532; B = 24 / 48:
+// +10 % / +13 %; 2048 hypotheses at B = 64 +8.5 %, 1024 at B = 64 +2 %, at B = 16 -10 %.  On fields with STRUCTURED errors (a third
+// of the object voting for a wrong point plus keypoints of very different quality: synth wrong_region / kp_outlier) the gain shrinks
+// to +3 % at B = 64 and turns into -6 % at B = 16, -2 % at B = 8 (profiles/r05_experiments.txt (8)).  So AUTO stages an estimate
+// only from kEstStageMinWork = 2e11 evaluations-equivalent on (B*K*hn*H*W: 18 LINEMOD frames at 4096 hypotheses, 540x720 / K = 17 /
+// 2048 at B = 16) and >= 1024 hypotheses; PVV_COUNT_STAGED_ESTIMATE forces it at every size (the tests' cross-check of the
+// bound), PVV_COUNT_FULL forbids it, and PVV_COUNT_STAGED means v3 alone.
+constexpr double kEstStageMinWork = 2e11;
+bool est_stage_auto(const pvv_problem *p) { return p->hn >= 1024 && stage_proxy_work(p) >= kEstStageMinWork; }
 //
 // kind: 0 = the pass must deliver every count (the estimate when its counts are an output, the fused un_pnp pass);
 //       1 = ransac_voting_layer_v3 proper, which keeps the arg-max and may count in stages;
@@ -618,7 +626,7 @@ int decide_staged(const pvv_problem *p, const Layout &L, hipStream_t st, int kin
 {
     if (!may_stage(p) || L.lead == 0) return 0;
     if (kind == 1 && stage_hint_allows(p, st)) return 1;
-    if (kind == 2 && p->count_kernel == PVV_COUNT_STAGED_ESTIMATE) return 2;
+    if (kind == 2 && (p->count_kernel == PVV_COUNT_STAGED_ESTIMATE || (p->count_kernel == PVV_COUNT_AUTO && est_stage_auto(p)))) return 2;
     return 0;
 }
 

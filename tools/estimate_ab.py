@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """estimate_voting_distribution_with_mean (4096 hypotheses, the un_pnp path of resnet18.py:72) with its count pass in full and in
-stages (PVV_COUNT_FULL / PVV_COUNT_STAGED / AUTO), one process, same batches: whole calls (HIP events around groups of calls, rotating
+stages (PVV_COUNT_FULL / PVV_COUNT_STAGED_ESTIMATE / AUTO), one process, same batches: whole calls (HIP events around groups of calls, rotating
 cold batches); covariances and PnP weights compared bit for bit.  One JSON object per case on stdout.
 
     python tools/estimate_ab.py [--cases cfg3:1,cfg3:8,cfg3:64] [--outlier 0.095] [--hn 4096]
@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--rotate", type=int, default=2)
     ap.add_argument("--hn", type=int, default=4096)
     ap.add_argument("--outlier", type=float, default=None)
+    ap.add_argument("--gen", default=None, help='JSON overrides of the synthetic generator, e.g. \'{"wrong_region": 0.3, "kp_outlier": [0.01, 0.4]}\'')
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     for case in args.cases.split(","):
@@ -44,12 +45,14 @@ def main():
         gen = {k: v for k, v in cfg.items() if k not in ("B", "hn")}
         if args.outlier is not None:
             gen["outlier"] = args.outlier
+        if args.gen:
+            gen.update({k: (tuple(v) if isinstance(v, list) else v) for k, v in json.loads(args.gen).items()})
         batches = [synth.make_batch(B=B, **gen, first_index=1000 * r, device=dev) for r in range(args.rotate)]
         for d in batches:
             d["mean"] = (d["kpt_2d"] + 0.3).contiguous()
-        row = {"case": case, "hn": args.hn, "K": K, "outlier": gen.get("outlier", 0.0)}
+        row = {"case": case, "hn": args.hn, "K": K, "outlier": gen.get("outlier", 0.0), "gen": args.gen}
         outs = {}
-        for name, mode in (("full", ext.COUNT_FULL), ("staged", ext.COUNT_STAGED), ("auto", ext.COUNT_AUTO)):
+        for name, mode in (("full", ext.COUNT_FULL), ("staged", ext.COUNT_STAGED_ESTIMATE), ("auto", ext.COUNT_AUTO)):
             def call(i):
                 d = batches[i % len(batches)]
                 return ext.estimate_voting_distribution(d["mask"], d["vertex"], d["mean"], args.hn, 0.99, 5, 30000, None, None, 7, False, 0, mode)
