@@ -790,8 +790,10 @@ def decode_leg(batches, ext, ransac_voting_layer_v3, B, H, W, K, hn, thresh, dev
 
 def un_pnp_leg(data, out, ext, ransac_voting_layer_v3, estimate_voting_distribution_with_mean, B, H, W, K, hn, thresh, dev, run, n):
     """The path cfg.test.un_pnp runs (resnet18.py:70-72), timed like the headline (pre-warm + barriered region): (a) the
-    reference's two calls on the argmax mask, (b) this library's one fused pass on seg logits + planar vertex; and the
-    estimate's own count pass (k_count_bf16<0>, 4096 hypotheses, always counted in full) with its VALU block."""
+    reference's two calls on the argmax mask (round 5: the library counts the estimate of a batch this large IN STAGES), (b)
+    decode_keypoint(un_pnp=True) on seg logits + planar vertex -- the library's own choice between the fused one-pass and the
+    two calls -- and (c) the fused one-pass forced; and the estimate's count pass inside calls, in full (k_count_bf16<0>, 4096
+    hypotheses: its VALU block) and as AUTO runs it."""
     from clean_pvnet_amd.decode import decode_keypoint
     mask, vertex = data["mask"], data["vertex"]
 
@@ -806,12 +808,24 @@ def un_pnp_leg(data, out, ext, ransac_voting_layer_v3, estimate_voting_distribut
     x[:, 2:] = vertex.permute(0, 3, 4, 1, 2).reshape(B, 2 * K, H, W)
     seg, ver = x[:, :2], x[:, 2:]
 
-    def one_pass(_i):
+    def auto_path(_i):
         return decode_keypoint({"seg": seg, "vertex": ver}, un_pnp=True)["var"]
+    el, _p, _o = run(auto_path, 2, n)
+    two = bool(ext.estimate_counts_in_stages(B, H, W, K, 4096, 30000))
+    res.update({"un_pnp_decode_keypoint_images_per_s": round(B * n / el, 1), "un_pnp_decode_keypoint_ms_per_step": round(1e3 * el / n, 4),
+                "un_pnp_decode_keypoint_path": "fused decode (argmax in the scan) + the estimate counted in stages: two calls" if two
+                                               else "one fused pass (pvv_decode_keypoint_un_pnp)"})
+    vtx = ver.permute(0, 2, 3, 1).view(B, H, W, K, 2)
+
+    def one_pass(_i):
+        return ext.decode_keypoint_un_pnp(seg, vtx, hn, 4096, thresh, 5, 30000, None, None, None, 7 + _i, ext.SINGULAR_REFERENCE, 0)[2]
     el, _p, _o = run(one_pass, 2, n)
     res.update({"un_pnp_fused_one_pass_images_per_s": round(B * n / el, 1), "un_pnp_fused_one_pass_ms_per_step": round(1e3 * el / n, 4)})
     del x
-    st = ext.stage_ms_in_pipeline([mask], [vertex], 4096, thresh, 5, 30000, 3, 10, ext.COUNT_AUTO, False, True)[4:]
+    sta = ext.stage_ms_in_pipeline([mask], [vertex], 4096, thresh, 5, 30000, 3, 10, ext.COUNT_AUTO, False, True)[4:]
+    res["estimate_4096_count_pass_as_auto_runs_it_ms"] = round(sorted(r[2] for r in sta)[len(sta) // 2], 4)
+    res["estimate_4096_counted_in_stages_by_auto"] = two
+    st = ext.stage_ms_in_pipeline([mask], [vertex], 4096, thresh, 5, 30000, 3, 10, ext.COUNT_FULL, False, True)[4:]
     med = lambda j: sorted(r[j] for r in st)[len(st) // 2]                         # noqa: E731
     est_ms = med(2)
     tn_e = ext.ransac_voting_v3(mask, vertex, hn, thresh, 5, 30000, None, None, 1, ext.SINGULAR_REFERENCE)[2].sum().item()
@@ -905,7 +919,7 @@ def extras_leg(extra, data, out, ext, synth, ransac_voting_layer_v3, estimate_vo
     extra["v3_plus_estimate_images_per_s"] = round(B * n2 / (time.perf_counter() - t2), 1)
     # the estimate's own count kernel (4096 hypotheses, always the full pass: the estimate weighs every hypothesis) as it
     # runs inside the calls, with its VALU roofline (the call the network makes with test.un_pnp)
-    st = ext.stage_ms_in_pipeline([mask], [vertex], 4096, thresh, 5, 30000, 3, 12, ext.COUNT_AUTO, False, True)[4:]
+    st = ext.stage_ms_in_pipeline([mask], [vertex], 4096, thresh, 5, 30000, 3, 12, ext.COUNT_FULL, False, True)[4:]
     est_ms = sorted(r[2] for r in st)[len(st) // 2]
     tn_e = ext.ransac_voting_v3(mask, vertex, hn, thresh, 5, 30000, None, None, 1, ext.SINGULAR_REFERENCE)[2].sum().item()
     evals_e = int(tn_e) * K * 4096

@@ -1087,6 +1087,13 @@ PVV_EXPORT int pvv_estimate_voting_distribution(const pvv_problem *p, const void
     return mark(p, PVV_MARK_END, st);
 }
 
+PVV_EXPORT int pvv_estimate_counts_in_stages(const pvv_problem *p)
+{
+    if (int e = validate(p)) return e < 0 ? e : -e;
+    if (!may_stage(p)) return 0;
+    return (p->count_kernel == PVV_COUNT_STAGED_ESTIMATE || (p->count_kernel == PVV_COUNT_AUTO && est_stage_auto(p))) ? 1 : 0;
+}
+
 // resnet18.py:65-72 with cfg.test.un_pnp as ONE pass (see the header): the row of every (image, keypoint) holds the hn
 // hypotheses of ransac_voting_layer_v3 followed by the hn_est of estimate_voting_distribution_with_mean.
 static pvv_problem un_pnp_problem(const pvv_problem *p, int32_t hn_est)

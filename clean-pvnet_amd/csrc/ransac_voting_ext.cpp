@@ -591,6 +591,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("count_kernel") = 0, py::arg("status") = py::none(), py::arg("cap") = py::none(), py::arg("out") = py::none());
     m.def("shutdown", []() { ok(pvv_shutdown(), "pvv_shutdown"); },
           "pvv_shutdown: release the library's per-device side streams, events and pinned stage-hint arrays; forget every hint");
+    m.def("estimate_counts_in_stages", [](int64_t B, int64_t H, int64_t W, int64_t K, int64_t hn, int64_t max_num) {
+              pvv_problem p;
+              memset(&p, 0, sizeof(p));
+              p.B = (int32_t)B; p.H = (int32_t)H; p.W = (int32_t)W; p.K = (int32_t)K; p.hn = (int32_t)hn;
+              p.mask_elem_size = 8; p.min_num = 5; p.max_num = (int32_t)max_num;
+              p.cap = pvv_default_cap(p.H, p.W, p.max_num); p.inlier_thresh = 0.99f;
+              return pvv_estimate_counts_in_stages(&p) == 1;
+          }, "pvv_estimate_counts_in_stages: would AUTO count an estimate of this size in stages? (host-only)", py::arg("B"), py::arg("H"),
+          py::arg("W"), py::arg("K"), py::arg("hn"), py::arg("max_num") = 30000);
     m.def("workspace_bytes", [](int64_t B, int64_t H, int64_t W, int64_t K, int64_t hn, int64_t max_num, int64_t mask_elem_size,
                                 int64_t count_kernel, bool device_rng) {
               pvv_problem p;

@@ -284,6 +284,12 @@ int pvv_estimate_voting_distribution(const pvv_problem *p, const void *d_mask,
  *   d_weights   [B,K,3] f32 (wxx,wxy,wyy) of inv(sqrtm(cov)) or NULL (evaluators/linemod/pvnet.py:118-128)
  * workspace: pvv_workspace_bytes_un_pnp(p, hn_est). */
 size_t pvv_workspace_bytes_un_pnp(const pvv_problem *p, int32_t hn_est);
+
+/* ABI v8: 1 when pvv_estimate_voting_distribution would count this problem IN STAGES (d_counts == NULL; PVV_COUNT_AUTO from
+ * ~2e11 evaluations-equivalent on, or PVV_COUNT_STAGED_ESTIMATE), 0 when it counts in full, < 0 for an invalid problem.  A host
+ * that can choose between the fused un_pnp pass (one FULL count pass over hn + hn_est hypotheses) and the two calls uses it:
+ * on large batches the two calls are faster because the estimate's pass shrinks (clean_pvnet_amd/decode.py). */
+int pvv_estimate_counts_in_stages(const pvv_problem *p);
 int pvv_decode_keypoint_un_pnp(const pvv_problem *p, int32_t hn_est, const float *d_seg,
                                const float *d_vertex, const int32_t *d_idxs,
                                const int32_t *d_idxs_est, const float *d_selection,

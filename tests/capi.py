@@ -57,6 +57,7 @@ def load():
         L.pvv_stream_read_probe.argtypes = [vp, sz, vp, vp]
         L.pvv_stage_hint_query.argtypes = [ctypes.POINTER(c_f32), ctypes.POINTER(c_f32), ctypes.POINTER(Problem), vp]
         L.pvv_shutdown.argtypes = []
+        L.pvv_estimate_counts_in_stages.argtypes = [ctypes.POINTER(Problem)]
         _lib = L
     return _lib
 

@@ -408,3 +408,33 @@ def test_estimate_counted_in_stages_equals_the_full_pass(synth, pkg, gpu, B, H, 
     a = ext.estimate_voting_distribution(m, v, mean, hn, 0.99, 5, 30000, None, None, 9, True, 0, ext.COUNT_STAGED_ESTIMATE)
     b = ext.estimate_voting_distribution(m, v, mean, hn, 0.99, 5, 30000, None, None, 9, True, 0, ext.COUNT_FULL)
     assert torch.equal(a[2], b[2]) and torch.equal(a[0], full[0])
+
+
+def test_auto_counts_a_large_estimate_in_stages_and_equals_the_full_pass(synth, pkg, gpu):
+    """Round 5: with the second launch at five blocks per CU the staged estimate wins from ~18 LINEMOD frames on, and AUTO takes it
+    (pvv_estimate_counts_in_stages).  24 frames, 4096 hypotheses: covariances and PnP weights equal the full pass bit for bit, the
+    stage marks show that the pass really ran in stages; 8 frames stay with the full pass; decode_keypoint(un_pnp=True) takes the
+    two calls exactly where the estimate is staged and gives the fused one-pass' results."""
+    from clean_pvnet_amd import decode_keypoint
+    from clean_pvnet_amd import ransac_voting as ext
+    assert ext.estimate_counts_in_stages(24, 480, 640, 9, 4096) and not ext.estimate_counts_in_stages(8, 480, 640, 9, 4096)
+    d = synth.make_batch(**{**synth.CONFIGS["cfg3"], "B": 24}, device=gpu)
+    m, v = d["mask"], d["vertex"]
+    mean = (d["kpt_2d"] + 0.25).contiguous()
+    full = ext.estimate_voting_distribution(m, v, mean, 4096, 0.99, 5, 30000, None, None, 9, False, 0, ext.COUNT_FULL)
+    auto = ext.estimate_voting_distribution(m, v, mean, 4096, 0.99, 5, 30000, None, None, 9, False, 0, ext.COUNT_AUTO)
+    assert torch.equal(auto[0], full[0]) and torch.equal(auto[4], full[4])
+    ms = ext.stage_ms_in_pipeline([m], [v], 4096, 0.99, 5, 30000, 3, 8, ext.COUNT_AUTO, True, True)
+    assert all(r[5] > 0 for r in ms)                                   # the first-launch mark was recorded: staged
+    ms8 = ext.stage_ms_in_pipeline([m[:8]], [v[:8]], 4096, 0.99, 5, 30000, 3, 8, ext.COUNT_AUTO, True, True)
+    assert all(r[5] < 0 for r in ms8)                                  # 8 frames: the full pass
+    x = torch.empty(24, 2 + 18, 480, 640, device=gpu)
+    x[:, 0] = 3.0 * (m == 0)
+    x[:, 1] = 3.0 * (m != 0)
+    x[:, 2:] = v.permute(0, 3, 4, 1, 2).reshape(24, 18, 480, 640)
+    out = decode_keypoint({"seg": x[:, :2], "vertex": x[:, 2:]}, un_pnp=True, weights=True, seed=77)
+    vtx = x[:, 2:].permute(0, 2, 3, 1).view(24, 480, 640, 9, 2)
+    kpt, mask, var, wts, _w, _t = ext.decode_keypoint_un_pnp(x[:, :2], vtx, 512, 4096, 0.99, 5, 30000, None, None, None, 77,
+                                                             ext.SINGULAR_REFERENCE, 0)
+    assert torch.equal(out["kpt_2d"], kpt) and torch.equal(out["mask"], mask) and torch.equal(out["var"], var)
+    assert torch.equal(out["var_weights"], wts)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """The two side paths of the bench line as a small profiling target (tools/profile_bench.sh runs it under rocprofv3):
-  * the un_pnp path of resnet18.py:70-72 as the reference runs it -- ransac_voting_layer_v3 (512 hypotheses) followed by
-    estimate_voting_distribution_with_mean (4096): its count kernel is k_count_bf16<0> at 4096 hypotheses, nothing else in
-    this process launches that instantiation;
+  * the un_pnp path of resnet18.py:70-72 -- ransac_voting_layer_v3 (512 hypotheses) followed by the estimate (4096) with its
+    count pass forced to the FULL kernel: k_count_bf16<0> at 4096 hypotheses, nothing else in this process launches that
+    instantiation;
   * the fused decode on the real caller's layout (seg logits + planar vertex: k_tile_scan_seg2, k_mask_from_lists on the
     side stream).
 BASELINE config 3 at B = 64, two rotating batches, 12 calls each after a warm-up."""
@@ -38,7 +38,10 @@ def main():
         for i in range(n):
             d = batches[i % 2]
             mean = ransac_voting_layer_v3(d["mask"], d["vertex"], hn, inlier_thresh=0.99)
-            estimate_voting_distribution_with_mean(d["mask"], d["vertex"], mean)
+            # the estimate's count pass IN FULL (PVV_COUNT_FULL): the 4096-hypothesis k_count_bf16<0> is the VALU-saturated kernel the
+            # counters are wanted for; AUTO counts an estimate of this size in stages since round 5, whose launches would mix with
+            # v3's of the same names in the trace
+            ext.estimate_voting_distribution(d["mask"], d["vertex"], mean, 4096, 0.99, 5, 30000, None, None, 7 + i, False, 0, ext.COUNT_FULL)
         for i in range(n):
             seg, vtx = nets[i % 2]
             ext.decode_keypoint_v3(seg, vtx, hn, 0.99, 5, 30000, None, None, 7 + i, ext.SINGULAR_REFERENCE)
