@@ -1,7 +1,7 @@
 #!/bin/bash
 # Second half of the evidence run: the bench lines again, AFTER tools/refresh_profiles.py has written profiles/call_pmc.json from
 # the PMC passes of evidence.sh on the same tree -- so that the lines' static counter figures are those of the committed profile.
-#   gpurun -- 'bash tools/evidence_bench.sh <tag>'   then   python tools/refresh_profiles.py - gpurun_out/<tag> r04 --bench-only
+#   gpurun -- 'bash tools/evidence_bench.sh <tag>'   then   python tools/refresh_profiles.py - gpurun_out/<tag> r05 --bench-only
 set -u
 TAG=${1:-evb}
 OUT=$PWD/gpurun_out/$TAG
