@@ -357,7 +357,7 @@ def main():
 
     # N = 1 extras that belong in the DEFAULT line:
     #  * the same call on fields with ~10 % outlier pixels (winner ratio rho ~ 0.90 instead of the clean 0.995): the staged
-    #    count's gain depends on clean fields, so the headline is quoted beside this one;
+    #    count's gain depends on clean fields (profiles/DESIGN_rounds_1-4.md 4.6), so the headline is quoted beside this one;
     #  * the path cfg.test.un_pnp runs (resnet18.py:70-72): v3 (512 hypotheses) + the 4096-hypothesis estimate, as the
     #    reference's two calls and as this library's one fused pass over seg logits + the planar vertex tensor.
     noisy, un_pnp = None, None
@@ -374,7 +374,7 @@ def main():
                  "auto_stage_threshold": round(hint[2], 4), "count_pass_staged_by_auto": bool(hint[0] and hint[1] >= hint[2]),
                  "vs_clean_headline": round((B * n3 / nz_el) / value, 4),
                  "what": "the timed call on 2 rotating batches whose foreground has 9.5 % random-direction (outlier) pixels; "
-                         "AUTO picks the count mode from the stage hint (DESIGN.md 4.6)"}
+                         "AUTO picks the count mode from the stage hint (profiles/DESIGN_rounds_1-4.md 4.6)"}
         del nb
         un_pnp = un_pnp_leg(batches[0], out, ext, ransac_voting_layer_v3, estimate_voting_distribution_with_mean, B, H, W, K, hn, thresh, dev,
                             run, max(4, args.steps // 25))

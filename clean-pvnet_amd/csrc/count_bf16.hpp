@@ -128,7 +128,7 @@ constexpr int kStageM = PVV_STAGE_M;
 constexpr uint32_t kStageFirst = PVV_STAGE_FIRST;
 // Round 4: with the second launch eliminating as it goes (count_filter_runs.hpp) a SMALLER first stage pays once its runs are
 // long: an eighth of the chunks ({1} of 8) instead of a quarter is -4 % per call at config 3 / B = 128 and -9 % on config 5 /
-// B = 16, +3 % at B = 64 and below (one-process A/B).  The schedule is a template parameter of the three kernels
+// B = 16, +3 % at B = 64 and below (one-process A/B, profiles/DESIGN_rounds_1-4.md 4.7).  The schedule is a template parameter of the three kernels
 // of the pass; the host picks it from the problem's size (launch_count_bf16).
 constexpr uint32_t kStageFirstEighth = 0x02u;
 constexpr uint32_t stage_rest_of(uint32_t first) { return ((1u << kStageM) - 1u) & ~first; }

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         }
         // The run length: as many chunks per run as still leave about target_items items (the size of the grid: one
         // generation of blocks), (total / R) * K >= target_items.  Measured on MI355X (one-process A/B of whole calls, config 3,
-        // forced run lengths): B = 64 -> R = 3 wins (1728 items; 2: +4 %, 5: +2 %, 9: +5 %), B = 32 -> 2 or 3,
+        // forced run lengths; profiles/DESIGN_rounds_1-4.md 4.7): B = 64 -> R = 3 wins (1728 items; 2: +4 %, 5: +2 %, 9: +5 %), B = 32 -> 2 or 3,
         // B = 128 -> 5, B = 16 -> 1, config 5 at B = 16 -> 9; the rule "at most ONE item per block" (longer runs: every item starts
         // at once, more elimination) lost 1-3 % at B = 16 ... 64.  run_r > 0 (tuning builds) forces the length.
         // Hypothesis groups per item: all of them when few hypotheses survive (ransac_voting_layer_v3: 15 % of 2048 are one pass), ONE

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
     //      the pixels of the rest that are inliers BEYOND DOUBT is one (<= its exact full count <= the maximum), and it needs
     //      neither the correctly rounded square roots and divisions of the exact vote (~50 VALU instructions per pixel and
     //      leader: two leaders made this kernel VALU-bound at 15 us) nor a fallback.  The test is the count kernel's second
-    //      level (count_bf16.hpp: t = a - kappa |d x nh| against a guard band, DESIGN.md 4.2) with the unit normal from
+    //      level (count_bf16.hpp: t = a - kappa |d x nh| against a guard band, DESIGN.md 4.1) with the unit normal from
     //      v_rsq_f32 (components within 4u, what that band assumes of an f32 normal: count_bf16.hpp) and TWICE its band: |t| - 2 beta2 a > 2 eps0
     //      and t > 0.  Pixels the exact vote rejects outright (K:121: norm1 < 1e-6, non-finite directions) have dd <= 4e-12
     //      or dd = inf/NaN and are not counted; what the band excludes (a few 1e-5 of the pixels) only lowers the bound.

@@ -219,7 +219,7 @@ double stage_proxy_work(const pvv_problem *p) { return (double)p->B * p->K * p->
 
 // ---------------------------------------------------------------------------------------------
 // The stage hint.  Whether staged counting pays depends on how clean the vector field is -- on the winners' inlier ratio
-// rho, which the host cannot know before the call: measured on MI355X (tools/staged_ab.py --outlier ..),
+// rho, which the host cannot know before the call: measured on MI355X (tools/staged_ab.py --outlier .., profiles/DESIGN_rounds_1-4.md 4.6),
 // 480x640, K = 9, 512 hypotheses at B = 64: +26 % at rho = 0.995, +5 % at 0.95, +-0 at 0.90, -4 % at 0.80 (a quarter of
 // the pixels then eliminates nothing and the call pays for the two extra launches); at B = 16 the break-even is rho ~
 // 0.97; 540x720, K = 17, 2048 hypotheses gains down to rho = 0.8 and below.  But consecutive calls see similar data (a
@@ -344,7 +344,7 @@ long long stage_hint_rest_chunks(const pvv_problem *p, hipStream_t st, uint32_t 
 }
 
 // The break-even winner ratio, from one-process A/B measurements of whole calls on MI355X with the round-4 second launch
-// (k_count_filter_runs; tools/staged_ab.py --outlier ..., profiles/r04_staged_ab_outliers.json): 480x640, K = 9,
+// (k_count_filter_runs; tools/staged_ab.py --outlier ..., profiles/r04_staged_ab_outliers.json, profiles/DESIGN_rounds_1-4.md 4.7): 480x640, K = 9,
 // 512 hypotheses breaks even at rho = 0.990 for B = 16, 0.966 for 24, 0.957 for 32, 0.91 for 48, 0.765 for 64 and below 0.6
 // for 128 (round 3's kernel: 0.976 / 0.941 / 0.906 at B = 16 / 32 / 64); 540x720, K = 17, 2048 hypotheses at B = 16 gains at
 // every ratio measured (+10 % at 0.71).  Interpolated in x = log2(B*K*hn*H*W / 2.26e10); more hypotheses per keypoint

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void k_select_refit(
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            // The re-vote decides like the count kernel's second level (count_bf16.hpp; DESIGN.md 4.2): t = a - kappa |d x n|
+            // The re-vote decides like the count kernel's second level (count_bf16.hpp; DESIGN.md 4.1): t = a - kappa |d x n|
             // with the unit direction from v_rsq_f32, taken when it lies outside the guard band (beta2, eps0) -- ~15 VALU
             // instructions -- and the exact sequence of K:100-125 (two square roots, a division: ~50) only inside the band
             // (4e-5 of the pixels), for a dead direction and for a winner beyond 1e15 px.  Same inlier set, bit for bit.

@@ -355,7 +355,7 @@ def test_count_kernel_isa_guard(tmp_path):
 
 def test_stage_hint_thresholds_and_no_data_without_a_gpu():
     """pvv_stage_hint_query: without a device there is no hint (returns 0, mean -1) and the threshold AUTO would compare it
-    with is the documented fit: 0.765 for config 3 at B = 64, 0.957 at B = 32, 0.990 at B = 16, 0.5 for
+    with is the documented fit (profiles/DESIGN_rounds_1-4.md 4.7): 0.765 for config 3 at B = 64, 0.957 at B = 32, 0.990 at B = 16, 0.5 for
     config 5 at B = 16, clamped to [0.5, 0.995]; 2.0 = never staged (too few evaluations)."""
     import ctypes
     from tests import capi

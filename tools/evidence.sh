@@ -19,7 +19,7 @@ python bench.py --no-cpu-baseline --extras --steps 50 > $OUT/bench_extras.json 2
 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_torchrun1.json 2> $OUT/bench_torchrun1.err
 python tools/config_bench.py --out $OUT/configs.json > $OUT/configs.log 2>&1
 bash tools/trace_rows.sh $TAG cfg2_B1 cfg3_B8_shard_of_8gpu cfg3_B64 default_path_hn128_maxnum100_B64 default_path_hn128_maxnum100_B1 cfg3_B64_decode_fused cfg2_B1_decode_fused cfg3_B64_planar_vertex > $OUT/gaps.log 2>&1
-# staged vs full count pass: the BASELINE configs, and config 3 / 5 over outlier fractions (AUTO's break-even)
+# staged vs full count pass: the BASELINE configs, and config 3 / 5 over outlier fractions (AUTO's break-even, profiles/DESIGN_rounds_1-4.md 4.7)
 python tools/staged_ab.py --cases cfg3:8,cfg3:16,cfg3:32,cfg3:64,cfg4:32,cfg5:16 --rotate 3 --out $OUT/staged_ab.json > $OUT/staged_ab.log 2>&1
 rm -f $OUT/staged_ab_outliers.jsonl
 for o in 0.03 0.05 0.095 0.2 0.3; do python tools/staged_ab.py --cases cfg3:16,cfg3:32,cfg3:64,cfg3:128,cfg5:16 --outlier $o --rotate 2 >> $OUT/staged_ab_outliers.jsonl 2>> $OUT/staged_ab.log; done

@@ -2,7 +2,7 @@
 // binary32 input: the largest error in units of the last place of the correctly rounded result, how many inputs are not
 // correctly rounded, and the largest error of the unit-normal component  nx = fl(dx * rsq(fl(dx^2 + dy^2)))  against the
 // true dx / |d| on a dense set of directions -- the number the guard bands of count_bf16.hpp / count_prune.hpp assume
-// (DESIGN.md 4.2: "f32 unit normal").
+// (DESIGN.md 4.1: "f32 unit normal").
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
