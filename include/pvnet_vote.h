@@ -177,7 +177,10 @@ typedef struct pvv_problem {
  *  - pvv_decode_keypoint_v3 / pvv_decode_keypoint_un_pnp on a two-class seg in two contiguous planes may write d_mask_out
  *    from a second, library-owned HIP stream (one per device, created on first use) that is forked from and joined back
  *    into `stream` inside the call: for the caller everything stays ordered on `stream`.  Not used while `stream` is being
- *    captured into a graph. */
+ *    captured into a graph.  (v8: joined back on EVERY exit path, errors included.  There is ONE side stream per device: calls
+ *    from several caller streams or threads fork onto it one after the other -- fork, launch and join record are one critical
+ *    section -- so the deferred masks of concurrent calls serialise among themselves, and a call's join may wait for a mask
+ *    kernel another call queued before it; the voting kernels of different streams stay independent.) */
 
 /* ABI v6.  ransac_voting_layer_v3 keeps only the arg-max of the counts (P:160-167), so pvv_ransac_voting_v3 /
  * pvv_decode_keypoint_v3 may count in STAGES: every hypothesis over a spread quarter of the pixels, then only the
@@ -186,8 +189,9 @@ typedef struct pvv_problem {
  * tie rule, winner count and refit are bit-identical to the full pass; what differs is that the counters of eliminated
  * hypotheses hold partial counts (they are not an output of v3).  AUTO stages when the batch is large enough for the
  * two extra launches to pay; FULL = the matrix-core kernel over everything, never staged; STAGED = staged wherever the
- * matrix-core kernel is valid (what the tests force at every size).  The estimate and the fused un_pnp pass weigh every
- * hypothesis and always count in full. */
+ * matrix-core kernel is valid (what the tests force at every size).  The fused un_pnp pass weighs every hypothesis and
+ * always counts in full; the estimate weighs those within 0.1 of the best ratio and, since ABI v8, counts in stages against that
+ * bound where it pays (AUTO on large batches: pvv_estimate_counts_in_stages; never when its counts are an output). */
 #define PVV_COUNT_FULL 2
 #define PVV_COUNT_STAGED 3
 /* ABI v8: PVV_COUNT_STAGED stages ransac_voting_layer_v3 only (its v6 meaning; under v7 it also staged an estimate whose
