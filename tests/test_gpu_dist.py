@@ -80,6 +80,18 @@ if comm is not None:
     torch.cuda.synchronize()
     direct.update(equal=bool(torch.equal(g, want)), copy=bool(torch.equal(recv, send)), copy2=bool(torch.equal(recv2, send)),
                   in_place=g.data_ptr() == buf.full.data_ptr())
+    # the whole step -- voting kernels + the exchange -- captured into ONE HIP graph and replayed (stream order is the only
+    # synchronisation of the direct call, so there is nothing a capture could not record)
+    cs = torch.cuda.Stream()
+    with torch.cuda.stream(cs):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=cs):
+            ransac_voting_layer_v3(d["mask"], d["vertex"], c["hn"], inlier_thresh=0.99, seed=4242, out=buf.mine)
+            gg = buf.gather()
+        buf.full.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    direct.update(graph_equal=bool(torch.equal(gg, want)))
     comm.destroy()
 torch.cuda.synchronize()
 print(json.dumps(dict(equal=bool(torch.equal(got, want)), split_equal=bool(torch.equal(both, want)), shape=list(got.shape),
@@ -101,7 +113,7 @@ def test_hip_layer_under_a_one_rank_nccl_group_equals_the_unsharded_call(gpu):
     assert res["shape"] == [5, 4, 2] and res["empty"] == [0, 4, 2] and res["err"] < 10
     dr = res["direct"]                                            # the ctypes RCCL communicator on a one-rank group
     assert dr["created"], dr
-    assert dr["equal"] and dr["copy"] and dr["copy2"] and dr["in_place"]
+    assert dr["equal"] and dr["copy"] and dr["copy2"] and dr["in_place"] and dr["graph_equal"]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
