@@ -791,9 +791,10 @@ def decode_leg(batches, ext, ransac_voting_layer_v3, B, H, W, K, hn, thresh, dev
 def un_pnp_leg(data, out, ext, ransac_voting_layer_v3, estimate_voting_distribution_with_mean, B, H, W, K, hn, thresh, dev, run, n):
     """The path cfg.test.un_pnp runs (resnet18.py:70-72), timed like the headline (pre-warm + barriered region): (a) the
     reference's two calls on the argmax mask (round 5: the library counts the estimate of a batch this large IN STAGES), (b)
-    decode_keypoint(un_pnp=True) on seg logits + planar vertex -- the library's own choice between the fused one-pass and the
-    two calls -- and (c) the fused one-pass forced; and the estimate's count pass inside calls, in full (k_count_bf16<0>, 4096
-    hypotheses: its VALU block) and as AUTO runs it."""
+    decode_keypoint(un_pnp=True) on seg logits + planar vertex -- ONE fused call (pvv_decode_keypoint_un_pnp) that, where the
+    estimate stages, counts its rows as two passes over the one compaction -- and (c) the same call with its single full count
+    pass forced; and the estimate's count pass inside calls, in full (k_count_bf16<0>, 4096 hypotheses: its VALU block) and as
+    AUTO runs it."""
     from clean_pvnet_amd.decode import decode_keypoint
     mask, vertex = data["mask"], data["vertex"]
 
@@ -813,12 +814,13 @@ def un_pnp_leg(data, out, ext, ransac_voting_layer_v3, estimate_voting_distribut
     el, _p, _o = run(auto_path, 2, n)
     two = bool(ext.estimate_counts_in_stages(B, H, W, K, 4096, 30000))
     res.update({"un_pnp_decode_keypoint_images_per_s": round(B * n / el, 1), "un_pnp_decode_keypoint_ms_per_step": round(1e3 * el / n, 4),
-                "un_pnp_decode_keypoint_path": "fused decode (argmax in the scan) + the estimate counted in stages: two calls" if two
-                                               else "one fused pass (pvv_decode_keypoint_un_pnp)"})
+                "un_pnp_decode_keypoint_path": "one fused call (pvv_decode_keypoint_un_pnp): one scan + compaction + hypothesis launch; " +
+                                               ("the rows counted as two passes -- v3's 512 columns, then the estimate's 4096 in stages" if two
+                                                else "one full count pass over all 4608 columns")})
     vtx = ver.permute(0, 2, 3, 1).view(B, H, W, K, 2)
 
     def one_pass(_i):
-        return ext.decode_keypoint_un_pnp(seg, vtx, hn, 4096, thresh, 5, 30000, None, None, None, 7 + _i, ext.SINGULAR_REFERENCE, 0)[2]
+        return ext.decode_keypoint_un_pnp(seg, vtx, hn, 4096, thresh, 5, 30000, None, None, None, 7 + _i, ext.SINGULAR_REFERENCE, 0, ext.COUNT_FULL)[2]
     el, _p, _o = run(one_pass, 2, n)
     res.update({"un_pnp_fused_one_pass_images_per_s": round(B * n / el, 1), "un_pnp_fused_one_pass_ms_per_step": round(1e3 * el / n, 4)})
     del x

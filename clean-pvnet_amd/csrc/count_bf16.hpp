@@ -143,6 +143,8 @@ struct StageArgs {
                           // (zeroed by k_compact_hyp; count_filter_runs.hpp)
     int sub_tenth;        // 1: the caller is estimate_voting_distribution_with_mean, which weighs every hypothesis whose ratio is
                           // within 0.1 of the best (P:262-264): the elimination bound is lowered accordingly (stage_bound)
+    int hstride;          // row length of hyps / counts / miss when the hn hypotheses counted are a column range of longer rows (the
+                          // fused un_pnp call counts its 512 + 4096 hypotheses as two passes over one compaction); 0: hn
 #ifdef PVV_STAMPS
     long long *dbg;       // instrumented builds: the phase census of k_count_filter_runs (count_filter_runs.hpp)
 #endif
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     const int lane = lane_id(), wave = wave_id();
     constexpr int PC = 4 * kBfPixPerWave;
     const int nt = (hn + 31) >> 5;                  // 32-hypothesis tiles per keypoint
+    const int hs = sa.hstride > 0 ? sa.hstride : hn; // row length of hyps / counts
     if constexpr (FILTER) if (*sa.any_staged == 0) return;
 
     // Work item = (image, keypoint, 512-pixel chunk, a run of hypothesis groups).  A group is up to 16 tiles (512
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         const int vi = nruns == 1 ? rem : rem / nruns;          // (one run per (chunk, keypoint) unless the batch is tiny)
         const int run = rem - vi * nruns;
         const int bk = b * K + vi;
-        const float2 *hyp_k = hyps + (size_t)bk * hn;
+        const float2 *hyp_k = hyps + (size_t)bk * hs;
         const float2 *crd = coords + (size_t)b * cap;
         const float2 *dir_k = dirs + (size_t)bk * cap;
         const int pb = chunk * PC;                              // first pixel of the block's chunk (< tn)
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             for (int q = 0; q < 2; ++q) {
                 const int i = tid + q * kBlock;
                 const int h = g0 * htpi * 32 + i;
-                if (i < nht0 * 32 && h < hn) cnt0[q] = counts[(size_t)bk * hn + h];
+                if (i < nht0 * 32 && h < hn) cnt0[q] = counts[(size_t)bk * hs + h];
             }
         }
         const int tn = __builtin_amdgcn_readfirstlane(tn_v);
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                     for (int q = 0; q < 2; ++q) {
                         const int i = threadIdx.x + q * kBlock;
                         const int h = ht0 * 32 + i;
-                        if (i < htpi * 32 && h < hn) { cnt[q] = counts[(size_t)bk * hn + h]; hp[q] = hyp_k[h]; }
+                        if (i < htpi * 32 && h < hn) { cnt[q] = counts[(size_t)bk * hs + h]; hp[q] = hyp_k[h]; }
                     }
                     far = stage_kept(g, cnt, hp);
                 } else {
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             for (int i = threadIdx.x; i < nslot; i += kBlock) {
                 const int v = sCnt[i];
                 const int c = FILTER ? v & 0xffff : v;               // (filter: index within the group << 16 | count <= 512)
-                if (c != 0) atomicAdd(&counts[(size_t)bk * hn + ht0 * 32 + (FILTER ? v >> 16 : i)], c);
+                if (c != 0) atomicAdd(&counts[(size_t)bk * hs + ht0 * 32 + (FILTER ? v >> 16 : i)], c);
             }
             PVV_STAMP(8);
         }

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     constexpr int GH = kRunSlots;                   // hypotheses per group
     constexpr uint32_t REST = stage_rest_of(FIRST);  // the chunks the first launch left
     const int nhg = (hn + GH - 1) / GH;             // hypothesis groups per keypoint
+    const int hs = sa.hstride > 0 ? sa.hstride : hn; // row length of hyps / counts / miss (StageArgs)
     if (*sa.any_staged == 0) return;
     PVV_FS_DECL();
 
@@ -159,11 +160,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         int r_img;
         const int b = locate_item(run_end, B, grun, &r_img);     // image, and the run's index within it
         const int bk = b * K + vi;
-        const float2 *hyp_k = hyps + (size_t)bk * hn;
+        const float2 *hyp_k = hyps + (size_t)bk * hs;
         const float2 *crd = coords + (size_t)b * cap;
         const float2 *dir_k = dirs + (size_t)bk * cap;
-        int *cnt_k = counts + (size_t)bk * hn;
-        int *miss_k = sa.miss + (size_t)bk * hn;
+        int *cnt_k = counts + (size_t)bk * hs;
+        int *miss_k = sa.miss + (size_t)bk * hs;
         const int tn = __builtin_amdgcn_readfirstlane(tn_arr[b]);
         const int nch = (tn + PC - 1) / PC;
         const int nrest = stage_chunks<REST>(nch);         // remaining chunks of the image (>= 1: the image is staged)

@@ -33,6 +33,7 @@ struct LeadArgs {
     int *lead;               // [B,K,8]
     const int *any_staged;   // one word written by k_count_bf16<kCountFirst>: 0 = no image of the batch is staged
     int K, hn, cap;
+    int hstride;             // row length of hyps / counts (>= hn; StageArgs.hstride)
     float kappa, beta, eps;  // the sure-inlier test below: kappa = T/sqrt(1-T^2), band = 2 x the count kernel's second level
     int nsplit;
 };
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
     int r0 = split * per + threadIdx.x;
     load_trip(r0);
     // ---- this wave's leader: maximal partial count, first index among ties
-    const int *cp = a.counts + (size_t)bk * a.hn;
+    const int *cp = a.counts + (size_t)bk * a.hstride;
     int best = -1, besth = 0x7fffffff;
     for (int h = threadIdx.x; h < a.hn; h += kBlock) {
         const int c = cp[h];
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void k_lead(LeadArgs a)
             }
     float2 ld[kLead];
 #pragma unroll
-    for (int w = 0; w < kLead; ++w) ld[w] = lc[w] >= 0 ? a.hyps[(size_t)bk * a.hn + li[w]] : make_float2(0.f, 0.f);
+    for (int w = 0; w < kLead; ++w) ld[w] = lc[w] >= 0 ? a.hyps[(size_t)bk * a.hstride + li[w]] : make_float2(0.f, 0.f);
     if (split == 0 && threadIdx.x < 4) {
         int v = -1;
 #pragma unroll

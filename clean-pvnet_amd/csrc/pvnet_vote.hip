@@ -102,6 +102,9 @@ bool may_store_draws(const pvv_problem *p, int T)
     return !((p->flags & PVV_FLAG_DEVICE_RNG) && fuse_sub_shape(p, T));
 }
 
+// one set of leader words: [B,K,8] + the any_staged word
+size_t lead_set_words(const pvv_problem *p) { return (size_t)p->B * p->K * 8 + 1; }
+
 Layout make_layout(const pvv_problem *p)
 {
     Layout L;
@@ -120,7 +123,8 @@ Layout make_layout(const pvv_problem *p)
     L.counts = take(sizeof(int) * (size_t)p->B * p->K * p->hn);
     L.sums = take(sizeof(double) * (size_t)p->B * p->K * kRefitSplitMax * 5);
     L.ratio = take(sizeof(float) * (size_t)p->B * p->K);
-    L.lead = may_stage(p) ? take(sizeof(int) * ((size_t)p->B * p->K * 8 + 1)) : 0;   // + the any_staged word
+    // (+ the any_staged word; TWO sets: the fused un_pnp call counts its v3 hypotheses and its estimate's as two staged passes)
+    L.lead = may_stage(p) ? take(sizeof(int) * 2 * lead_set_words(p)) : 0;
     L.miss = may_stage(p) ? take(sizeof(int) * (size_t)p->B * p->K * p->hn) : 0;
     L.total = off;
     return L;
@@ -461,6 +465,7 @@ struct StagedLaunch {
     long long *dbg;
     int per_cu_first, per_cu_filter, target_first, target_filter;
     int sub_tenth;       // 1: the estimate's bound (StageArgs.sub_tenth)
+    int col0, hstride, lead_set;   // CountCols (0, 0, 0: whole rows of p->hn hypotheses)
 };
 
 // the three launches of a staged count pass for one chunk schedule (FIRST = the residues mod 8 the first launch counts)
@@ -473,15 +478,16 @@ int launch_staged(const StagedLaunch &a)
     hipStream_t st = a.st;
     const Bf16Consts fc = a.fc;
     const float2 *coords = (const float2 *)(ws + L.coords), *dirs = (const float2 *)(ws + L.dirs);
-    const float2 *hyps = (const float2 *)(ws + L.hyps);
-    int *counts = (int *)(ws + L.counts);
+    const float2 *hyps = (const float2 *)(ws + L.hyps) + a.col0;
+    int *counts = (int *)(ws + L.counts) + a.col0;
     const int *tn = (const int *)(ws + L.tn);
-    int *lead = (int *)(ws + L.lead);
+    int *lead = (int *)(ws + L.lead) + (size_t)a.lead_set * lead_set_words(p);
     StageArgs sa;
     sa.lead = nullptr;
     sa.any_staged = lead + (size_t)p->B * p->K * 8;
-    sa.miss = (int *)(ws + L.miss);
+    sa.miss = (int *)(ws + L.miss) + a.col0;
     sa.sub_tenth = a.sub_tenth;
+    sa.hstride = a.hstride;
 #ifdef PVV_STAMPS
     sa.dbg = tuning_ptr("PVV_DBG_PTR_FILTER");                    // phase census of the second launch (tools/census_filter.py)
 #endif
@@ -492,6 +498,7 @@ int launch_staged(const StagedLaunch &a)
     LeadArgs la;
     la.tn_arr = tn; la.coords = coords; la.dirs = dirs; la.hyps = hyps; la.counts = counts; la.lead = lead;
     la.K = p->K; la.hn = p->hn; la.cap = p->cap;
+    la.hstride = a.hstride > 0 ? a.hstride : p->hn;
     la.kappa = fc.kappa; la.beta = 2.f * fc.beta2; la.eps = 2.f * fc.eps0;
     la.any_staged = sa.any_staged;
     // shares per (image, keypoint): the largest power of two <= 16 that keeps the grid within one generation of blocks
@@ -522,7 +529,17 @@ int launch_staged(const StagedLaunch &a)
     return check_launch("k_count_bf16<filter>");
 }
 
-int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, int staged /*0: full pass, 1: v3 in stages, 2: the estimate in stages*/)
+// The hypotheses a count pass covers when they are a column range of longer rows: the fused un_pnp call keeps rows of
+// hn + hn_est hypotheses (one compaction, one hypothesis launch) and counts [0, hn) as ransac_voting_layer_v3's and [hn, hn + hn_est)
+// as the estimate's, each full or in stages as it would be alone.  p->hn is then the number of columns counted, hstride the row.
+struct CountCols {
+    int col0 = 0;        // first column
+    int hstride = 0;     // row length (0: p->hn, whole rows)
+    int lead_set = 0;    // which of the workspace's two sets of leader words the pass uses
+};
+
+int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, int staged /*0: full pass, 1: v3 in stages, 2: the estimate in stages*/,
+                      const CountCols &cc = CountCols())
 {
     // persistent blocks per CU (5 are resident): every block builds the item table once, so few blocks are better when
     // items are short (hn <= 512: one hypothesis group per item), more when they are long and uneven; several
@@ -553,8 +570,8 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     // (not few at B <= 8 -- only the hint can say so --: 15 per CU whatever hn; config 5 at B = 2, staged: 48 per CU +2 %)
     const int per_cu = per_cu_t > 0 ? per_cu_t : (few ? 5 : ((p->hn < 2048 || p->B <= 8) ? 15 : 48));
     const float2 *coords = (const float2 *)(ws + L.coords), *dirs = (const float2 *)(ws + L.dirs);
-    const float2 *hyps = (const float2 *)(ws + L.hyps);
-    int *counts = (int *)(ws + L.counts);
+    const float2 *hyps = (const float2 *)(ws + L.hyps) + cc.col0;
+    int *counts = (int *)(ws + L.counts) + cc.col0;
     const int *tn = (const int *)(ws + L.tn);
     const Bf16Consts fc = bf16_consts(p->inlier_thresh);
     const int target = tuning_int("PVV_TARGET_ITEMS", items_per_cu * num_cus());
@@ -566,8 +583,10 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     const int per_cu_filter = tuning_int("PVV_GRID_PER_CU_FILTER", p->hn < 2048 ? 5 : per_cu);
     long long *dbg = tuning_ptr("PVV_DBG_PTR");
     if (!staged) {
+        StageArgs full{};
+        full.hstride = cc.hstride;
         hipLaunchKernelGGL(k_count_bf16<kCountFull>, dim3(per_cu * num_cus()), dim3(kBlock), 0, st, coords, dirs, hyps, counts, tn,
-                           p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target, dbg, StageArgs{nullptr, nullptr});
+                           p->B, p->K, p->hn, p->cap, p->inlier_thresh, fc, target, dbg, full);
         return check_launch("k_count_bf16");
     }
     // ransac_voting_layer_v3, staged: count a spread part of the chunks for every hypothesis, bound the winner's count from
@@ -579,6 +598,7 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     sl.p = p; sl.ws = ws; sl.L = &L; sl.st = st; sl.fc = fc; sl.dbg = dbg;
     sl.per_cu_first = per_cu_first; sl.per_cu_filter = per_cu_filter; sl.target_first = target_first; sl.target_filter = target_filter;
     sl.sub_tenth = staged == 2 ? 1 : 0;
+    sl.col0 = cc.col0; sl.hstride = cc.hstride; sl.lead_set = cc.lead_set;
     const bool eighth = tuning_int("PVV_STAGE_EIGHTH", (p->count_kernel == PVV_COUNT_AUTO ? stage_work(p, st) : stage_proxy_work(p)) >= 2.26e10 * 4.757 ? 1 : 0) != 0;
     return eighth ? launch_staged<kStageFirstEighth>(sl) : launch_staged<kStageFirst>(sl);
 }
@@ -630,11 +650,12 @@ int decide_staged(const pvv_problem *p, const Layout &L, hipStream_t st, int kin
     return 0;
 }
 
-int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, int staged)
+int launch_count_any(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, int staged, const CountCols &cc = CountCols())
 {
     if (p->ev_count_begin && hipEventRecord((hipEvent_t)p->ev_count_begin, st) != hipSuccess)
         return fail(PVV_E_ARG, "ev_count_begin is not a valid hipEvent_t");
-    const int e = use_bf16_count(p) ? launch_count_bf16(p, L, ws, st, staged) : launch_count(planar_count_args(p, L, ws), st);
+    if (!use_bf16_count(p) && (cc.col0 || cc.hstride)) return fail(PVV_E_ARG, "internal: a column range needs the bf16 count kernel");
+    const int e = use_bf16_count(p) ? launch_count_bf16(p, L, ws, st, staged, cc) : launch_count(planar_count_args(p, L, ws), st);
     if (e) return e;
     if (p->ev_count_end && hipEventRecord((hipEvent_t)p->ev_count_end, st) != hipSuccess)
         return fail(PVV_E_ARG, "ev_count_end is not a valid hipEvent_t");
@@ -848,12 +869,20 @@ struct SideJoin {
     }
 };
 
+// What run_front launches as "the count pass" when it is not one pass over whole rows: the first of the fused un_pnp call's two
+// passes (pvv_decode_keypoint_un_pnp); the caller launches the second one itself.
+struct CountPlan {
+    const pvv_problem *p;    // the problem of that pass: p->hn columns of rows of cols.hstride
+    int staged;              // decide_staged() for it
+    CountCols cols;
+};
+
 // mask scan + (subsample) + compaction and hypotheses + counting, shared by both layers.
 int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d_vertex,
               const int32_t *d_idxs, const float *d_selection, char *ws, const Layout &L,
               hipStream_t st, int32_t *d_tn, const float *d_seg = nullptr, int64_t *d_mask_out = nullptr,
               const int32_t *d_idxs2 = nullptr, int hn_first = -1, uint32_t stream_first = 1u, uint32_t stream_rest = 3u,
-              int stage_kind = 0 /*decide_staged's kind*/)
+              int stage_kind = 0 /*decide_staged's kind*/, const CountPlan *plan = nullptr)
 {
     if ((p->flags & PVV_FLAG_DEVICE_RNG) && (d_idxs || d_idxs2 || d_selection))
         return fail(PVV_E_ARG, "PVV_FLAG_DEVICE_RNG promises d_idxs = d_idxs_est = d_selection = NULL");
@@ -862,7 +891,8 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
     if (f.m.want_draws && L.tile_draw == 0) return fail(PVV_E_WORKSPACE, "workspace holds no draw storage for this call");   // (cannot happen: may_store_draws)
     // whether the count pass runs in stages is decided HERE, once: a call that will not stage neither zeroes nor reads the
     // miss counters and leader words (k_compact_hyp would otherwise clear B*K*hn words for nothing on every AUTO call)
-    const int staged = decide_staged(p, L, st, stage_kind);
+    // (a plan: some pass of the call stages -- the caller decided -- so the words are zeroed for all columns)
+    const int staged = plan ? 1 : decide_staged(p, L, st, stage_kind);
     if (!staged) { f.h.miss = nullptr; f.h.lead = nullptr; }
     if (int e = mark(p, PVV_MARK_BEGIN, st)) return e;
     SideJoin sj;
@@ -906,7 +936,7 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
         }
         if (le) return le;
     }
-    if (int e = launch_count_any(p, L, ws, st, staged)) return e;
+    if (int e = plan ? launch_count_any(plan->p, L, ws, st, plan->staged, plan->cols) : launch_count_any(p, L, ws, st, staged)) return e;
     if (int e = sj.finish()) return e;
     return mark(p, PVV_MARK_COUNT, st);
 }
@@ -1129,10 +1159,35 @@ PVV_EXPORT int pvv_decode_keypoint_un_pnp(const pvv_problem *p, int32_t hn_est, 
     if (!d_kpt || !d_cov) return fail(PVV_E_ARG, "d_kpt / d_cov is NULL");
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)d_workspace;
-    if (int e = run_front(&q, 0, nullptr, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, d_seg, d_mask_out, d_idxs_est,
-                          p->hn))
-        return e;
-    if (int e = finish_v3(p, L, ws, d_kpt, d_win_counts, st, q.hn)) return e;      // mean = winner refit over the first hn
+    // Round 5: when the estimate alone would count in stages (decide_staged: large batches, AUTO; or forced) the rows are counted
+    // as TWO passes over the one compaction -- columns [0, hn) as ransac_voting_layer_v3 would (full or in stages, the same rule
+    // and the same stage hint as the layer's own call), then, behind the refit that delivers the mean, columns [hn, hn + hn_est)
+    // against the estimate's bound.  Same results as the one full pass over all columns, bit for bit; what the two separate calls
+    // cost more -- a second mask scan and a second compaction -- stays saved.
+    pvv_problem pe = *p;
+    pe.hn = hn_est;
+    const int est_staged = decide_staged(&pe, L, st, 2);
+    if (est_staged) {
+        const size_t set_bytes = sizeof(int) * lead_set_words(p);
+        // the second pass's leader words (k_compact_hyp zeroes the first set): cleared up front, off the kernels' chain
+        if (hipMemsetAsync(ws + L.lead + set_bytes, 0, set_bytes, st) != hipSuccess) return fail(PVV_E_ARG, "hipMemsetAsync(leader words) failed");
+        CountPlan plan;
+        plan.p = p;
+        plan.staged = decide_staged(p, L, st, 1);
+        plan.cols.col0 = 0; plan.cols.hstride = q.hn; plan.cols.lead_set = 0;
+        if (int e = run_front(&q, 0, nullptr, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, d_seg, d_mask_out, d_idxs_est,
+                              p->hn, 1u, 3u, 0, &plan))
+            return e;
+        if (int e = finish_v3(p, L, ws, d_kpt, d_win_counts, st, q.hn)) return e;
+        CountCols ec;
+        ec.col0 = p->hn; ec.hstride = q.hn; ec.lead_set = 1;
+        if (int e = launch_count_any(&pe, L, ws, st, est_staged, ec)) return e;
+    } else {
+        if (int e = run_front(&q, 0, nullptr, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, d_seg, d_mask_out, d_idxs_est,
+                              p->hn))
+            return e;
+        if (int e = finish_v3(p, L, ws, d_kpt, d_win_counts, st, q.hn)) return e;      // mean = winner refit over the first hn
+    }
     hipLaunchKernelGGL(k_covariance, dim3(p->K, p->B), dim3(kBlock), 0, st, (const int *)(ws + L.tn),
                        (const float2 *)(ws + L.hyps), (const int *)(ws + L.counts), (const float2 *)d_kpt, d_cov,
                        (float2 *)nullptr, (int *)nullptr, d_weights, p->K, (int)hn_est, q.hn, p->hn);
@@ -1158,7 +1213,7 @@ PVV_EXPORT int pvv_rerun_count_kernel(const pvv_problem *p, void *d_workspace, s
     char *ws = (char *)d_workspace;
     if (zero_counts) {
         hipError_t e = hipMemsetAsync(ws + L.counts, 0, sizeof(int) * (size_t)p->B * p->K * p->hn, st);
-        if (e == hipSuccess && L.lead) e = hipMemsetAsync(ws + L.lead, 0, sizeof(int) * ((size_t)p->B * p->K * 8 + 1), st);
+        if (e == hipSuccess && L.lead) e = hipMemsetAsync(ws + L.lead, 0, sizeof(int) * lead_set_words(p), st);
         if (e == hipSuccess && L.miss) e = hipMemsetAsync(ws + L.miss, 0, sizeof(int) * (size_t)p->B * p->K * p->hn, st);
         if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     }

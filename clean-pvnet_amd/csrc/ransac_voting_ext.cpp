@@ -333,7 +333,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_v3(
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> decode_keypoint_un_pnp(
     at::Tensor seg, at::Tensor vertex, int64_t round_hyp_num, int64_t hyp_est, double inlier_thresh, int64_t min_num,
     int64_t max_num, std::optional<at::Tensor> idxs, std::optional<at::Tensor> idxs_est,
-    std::optional<at::Tensor> selection, int64_t seed, int64_t singular_policy, int64_t first_image)
+    std::optional<at::Tensor> selection, int64_t seed, int64_t singular_policy, int64_t first_image, int64_t count_kernel)
 {
     const c10::DeviceGuard device_guard(vertex.device());
     TORCH_CHECK(seg.is_cuda(), "seg must be a CUDA tensor");
@@ -345,6 +345,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tenso
     auto mask = at::empty({seg.size(0), seg.size(2), seg.size(3)}, seg.options().dtype(at::kLong));
     pvv_problem p = make_problem(mask, vertex, round_hyp_num, inlier_thresh, min_num, max_num, singular_policy, seed);
     p.first_image = (int32_t)first_image;
+    p.count_kernel = (int32_t)count_kernel;
     p.seg_classes = (int32_t)seg.size(1);
     for (int i = 0; i < 4; ++i) p.seg_stride[i] = seg.stride(i);
     cap_for_selection(selection, p);
@@ -620,7 +621,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           "argmax(seg) + ransac_voting_layer_v3 + estimate_voting_distribution_with_mean in one pass (two-class seg)",
           py::arg("seg"), py::arg("vertex"), py::arg("round_hyp_num"), py::arg("hyp_est"), py::arg("inlier_thresh"),
           py::arg("min_num"), py::arg("max_num"), py::arg("idxs"), py::arg("idxs_est"), py::arg("selection"), py::arg("seed"),
-          py::arg("singular_policy"), py::arg("first_image") = 0);
+          py::arg("singular_policy"), py::arg("first_image") = 0, py::arg("count_kernel") = 0);
     m.def("estimate_voting_distribution", &estimate_voting_distribution,
           "batched estimate_voting_distribution_with_mean", py::arg("mask"), py::arg("vertex"), py::arg("mean"),
           py::arg("hyp_total"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"), py::arg("idxs"),

@@ -23,11 +23,13 @@ def decode_keypoint(output, un_pnp=False, *, idxs=None, selection=None, singular
     slices of one network output tensor (resnet18.py:93-94), no copy is made.
 
     ``un_pnp`` with a two-class ``seg`` (PVNet's) runs ``ransac_voting_layer_v3`` and
-    ``estimate_voting_distribution_with_mean`` (resnet18.py:71-72) as ONE pass -- one mask scan, one compaction, one
-    hypothesis and one inlier-count launch for the 512 + 4096 hypotheses -- with results bit-identical to the two calls
-    on the same draws; on batches large enough for the library to count the estimate IN STAGES (round 5:
-    ``pvv_estimate_counts_in_stages``, ~18 LINEMOD frames on) the two calls are taken instead -- the fused pass counts all
-    4608 hypotheses in full, the staged estimate drops a third of that work (1.43 vs 1.59 ms at B = 64), same results; ``idxs_est`` [b,4096,vn,2] injects the estimate's index pairs like ``idxs`` does for v3, and
+    ``estimate_voting_distribution_with_mean`` (resnet18.py:71-72) as ONE call -- one mask scan, one compaction, one
+    hypothesis launch for the 512 + 4096 hypotheses -- with results bit-identical to the two calls on the same draws.  Small
+    batches count all 4608 hypotheses in one launch; on batches large enough for the library to count the estimate IN STAGES
+    (``pvv_estimate_counts_in_stages``, ~18 LINEMOD frames on) the same call counts the rows as two passes over the one
+    compaction -- v3's 512 columns as the layer would, then the estimate's 4096 against its own bound -- and keeps the saved
+    scan and compaction (round 5; before, the two separate calls were taken there).  ``idxs_est`` [b,4096,vn,2] injects the
+    estimate's index pairs like ``idxs`` does for v3, and
     ``weights=True`` also stores ``var_weights`` [b,vn,3] = (wxx,wxy,wyy) of ``inv(sqrtm(var))``, what the evaluator
     feeds uncertainty_pnp (evaluators/linemod/pvnet.py:118-130).
 
@@ -52,7 +54,7 @@ def decode_keypoint(output, un_pnp=False, *, idxs=None, selection=None, singular
         sl = slice(lo, hi)
         cut = lambda t: None if t is None else t[sl]                          # noqa: E731
         first = int(first_image) + lo
-        if fused and not _ext.estimate_counts_in_stages(hi - lo, h, w, vn_2 // 2, 4096, 30000):
+        if fused:
             # resnet18.py:71-72 fused; the estimate's defaults (P:202): ceil(4096 / 256) rounds of 256 hypotheses
             kpt, mask, var, wts, _win, _tn = _ext.decode_keypoint_un_pnp(segf[sl], vertex[sl], 512, 4096, 0.99, 5, 30000,
                                                                          cut(idxs), cut(idxs_est), cut(selection), seed,

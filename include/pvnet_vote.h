@@ -280,6 +280,10 @@ int pvv_estimate_voting_distribution(const pvv_problem *p, const void *d_mask,
  * (= ceil(min_hyp_num / round_hyp_num) * round_hyp_num, 4096 by default) of the estimate; the refit reads the
  * first p->hn counts of a row, the covariance the rest.  Results are bit-identical to pvv_decode_keypoint_v3
  * followed by pvv_estimate_voting_distribution on the same draws.
+ * Where the estimate alone would count in stages (pvv_estimate_counts_in_stages(p with hn = hn_est): large batches under
+ * PVV_COUNT_AUTO, or PVV_COUNT_STAGED_ESTIMATE) the rows are counted as TWO passes over the one compaction instead: the
+ * columns [0, p->hn) exactly as pvv_ransac_voting_v3 would count them (in full or in stages, the same rule and stage hint),
+ * then, behind the refit, the columns [p->hn, p->hn + hn_est) against the estimate's bound.  Same results, bit for bit.
  * Requires p->seg_classes == 2 (PVNet's seg_dim, config.py:108-112): v3 votes with `mask != 0`, the estimate with
  * `mask == 1` (P:125 vs P:207), which coincide only for a two-class argmax -- PVV_E_ARG otherwise (make the two
  * calls then).  min_num / max_num of p apply to both layers, as in the reference's call (defaults of both).
@@ -290,9 +294,9 @@ int pvv_estimate_voting_distribution(const pvv_problem *p, const void *d_mask,
 size_t pvv_workspace_bytes_un_pnp(const pvv_problem *p, int32_t hn_est);
 
 /* ABI v8: 1 when pvv_estimate_voting_distribution would count this problem IN STAGES (d_counts == NULL; PVV_COUNT_AUTO from
- * ~2e11 evaluations-equivalent on, or PVV_COUNT_STAGED_ESTIMATE), 0 when it counts in full, < 0 for an invalid problem.  A host
- * that can choose between the fused un_pnp pass (one FULL count pass over hn + hn_est hypotheses) and the two calls uses it:
- * on large batches the two calls are faster because the estimate's pass shrinks (clean_pvnet_amd/decode.py). */
+ * ~2e11 evaluations-equivalent on, or PVV_COUNT_STAGED_ESTIMATE), 0 when it counts in full, < 0 for an invalid problem.
+ * pvv_decode_keypoint_un_pnp applies the same rule to its estimate columns (see there), so a host no longer has to choose
+ * between the fused call and the two calls; the query stays for hosts that want to know which pass will run. */
 int pvv_estimate_counts_in_stages(const pvv_problem *p);
 int pvv_decode_keypoint_un_pnp(const pvv_problem *p, int32_t hn_est, const float *d_seg,
                                const float *d_vertex, const int32_t *d_idxs,

@@ -116,7 +116,8 @@ def v3(mask, vertex, hn, thresh, idxs=None, selection=None, **kw):
     return out, win, tn
 
 
-def estimate(mask, vertex, mean, hn_total, thresh, idxs=None, selection=None, **kw):
+def estimate(mask, vertex, mean, hn_total, thresh, idxs=None, selection=None, want_counts=True, **kw):
+    """want_counts=False: no hypothesis / count outputs (NULL) -- only then may the pass count in stages."""
     import torch
     L = load()
     if selection is not None:
@@ -131,6 +132,6 @@ def estimate(mask, vertex, mean, hn_total, thresh, idxs=None, selection=None, **
     counts = torch.empty(p.B, p.K, hn_total, dtype=torch.int32, device=dev)
     tn = torch.empty(p.B, dtype=torch.int32, device=dev)
     check(L.pvv_estimate_voting_distribution(ctypes.byref(p), ptr(mask), ptr(vertex), ptr(idxs), ptr(selection),
-                                             ptr(mean), ptr(ws), n, ptr(cov), ptr(hyp), ptr(counts), ptr(tn),
-                                             None, stream()))
+                                             ptr(mean), ptr(ws), n, ptr(cov), ptr(hyp) if want_counts else None,
+                                             ptr(counts) if want_counts else None, ptr(tn), None, stream()))
     return cov, hyp, counts, tn

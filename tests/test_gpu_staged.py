@@ -413,8 +413,8 @@ def test_estimate_counted_in_stages_equals_the_full_pass(synth, pkg, gpu, B, H, 
 def test_auto_counts_a_large_estimate_in_stages_and_equals_the_full_pass(synth, pkg, gpu):
     """Round 5: with the second launch at five blocks per CU the staged estimate wins from ~18 LINEMOD frames on, and AUTO takes it
     (pvv_estimate_counts_in_stages).  24 frames, 4096 hypotheses: covariances and PnP weights equal the full pass bit for bit, the
-    stage marks show that the pass really ran in stages; 8 frames stay with the full pass; decode_keypoint(un_pnp=True) takes the
-    two calls exactly where the estimate is staged and gives the fused one-pass' results."""
+    stage marks show that the pass really ran in stages; 8 frames stay with the full pass; decode_keypoint(un_pnp=True) is the one
+    fused call at every size (which then counts its rows as two passes, see the next test) and equals the two separate calls."""
     from clean_pvnet_amd import decode_keypoint
     from clean_pvnet_amd import ransac_voting as ext
     assert ext.estimate_counts_in_stages(24, 480, 640, 9, 4096) and not ext.estimate_counts_in_stages(8, 480, 640, 9, 4096)
@@ -438,3 +438,43 @@ def test_auto_counts_a_large_estimate_in_stages_and_equals_the_full_pass(synth, 
                                                              ext.SINGULAR_REFERENCE, 0)
     assert torch.equal(out["kpt_2d"], kpt) and torch.equal(out["mask"], mask) and torch.equal(out["var"], var)
     assert torch.equal(out["var_weights"], wts)
+    # ... and the two separate calls under the same seed (the fused call draws what they draw)
+    kpt2, mask2, _w2, _t2 = ext.decode_keypoint_v3(x[:, :2], vtx, 512, 0.99, 5, 30000, None, None, 77, ext.SINGULAR_REFERENCE)
+    est = ext.estimate_voting_distribution(mask2, vtx, kpt2, 4096, 0.99, 5, 30000, None, None, 77, False, 0, ext.COUNT_FULL)
+    assert torch.equal(kpt, kpt2) and torch.equal(mask, mask2) and torch.equal(var, est[0]) and torch.equal(wts, est[4])
+
+
+@pytest.mark.parametrize("B,H,W,K,hn,hn_est,fg,outlier", [(3, 480, 640, 9, 512, 4096, 0.02, 0.0), (6, 240, 320, 4, 200, 1100, 0.12, 0.2),
+                                                          (2, 540, 720, 5, 128, 2048, 0.08, 0.05), (5, 200, 300, 3, 64, 700, (0.02, 0.3), 0.0)])
+def test_fused_un_pnp_rows_counted_as_two_passes_equal_the_one_full_pass(synth, pkg, gpu, B, H, W, K, hn, hn_est, fg, outlier):
+    """pvv_decode_keypoint_un_pnp keeps rows of hn + hn_est hypotheses from ONE compaction.  Where the estimate counts in stages
+    (AUTO on large batches; forced here with PVV_COUNT_STAGED_ESTIMATE, which also forces v3's columns into stages) the rows are
+    counted as two passes over column ranges -- [0, hn) against the arg-max bound, [hn, hn + hn_est) against the estimate's --
+    with their own leader words: keypoints, winner counts, covariances and PnP weights equal the one full pass over all columns
+    bit for bit, on repeated calls (the second set of leader words is re-zeroed per call), with injected index pairs too."""
+    from clean_pvnet_amd import ransac_voting as ext
+    d = synth.make_batch(B=B, H=H, W=W, K=K, fg=fg, sigma=0.05, outlier=outlier, seed=6100 + B, device=gpu)
+    m, v = d["mask"], d["vertex"]
+    x = torch.empty(B, 2 + 2 * K, H, W, device=gpu)
+    x[:, 0] = 3.0 * (m == 0)
+    x[:, 1] = 3.0 * (m != 0)
+    x[:, 2:] = v.permute(0, 3, 4, 1, 2).reshape(B, 2 * K, H, W)
+    seg, vtx = x[:, :2], x[:, 2:].permute(0, 2, 3, 1).view(B, H, W, K, 2)
+    run = lambda ck, i0=None, i1=None: ext.decode_keypoint_un_pnp(seg, vtx, hn, hn_est, 0.99, 5, 30000, i0, i1, None, 31,   # noqa: E731
+                                                                  ext.SINGULAR_REFERENCE, 0, ck)
+    full = run(ext.COUNT_FULL)
+    for rep in range(3):
+        st = run(ext.COUNT_STAGED_ESTIMATE)
+        for a_, b_, nm in zip(st, full, ("keypoints", "mask", "covariances", "weights", "winner counts", "tn")):
+            assert torch.equal(a_, b_), (nm, rep)
+    # PVV_COUNT_STAGED is v3's alone: the fused call then counts everything in one full pass, as before
+    st = run(ext.COUNT_STAGED)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(st, full))
+    # injected index pairs for both parts
+    g = torch.Generator().manual_seed(5)
+    tn_min = int(full[5].min().item())
+    if tn_min > 0:
+        i0 = torch.randint(0, tn_min, (B, hn, K, 2), generator=g, dtype=torch.int32).to(gpu)
+        i1 = torch.randint(0, tn_min, (B, hn_est, K, 2), generator=g, dtype=torch.int32).to(gpu)
+        a, b = run(ext.COUNT_FULL, i0, i1), run(ext.COUNT_STAGED_ESTIMATE, i0, i1)
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(a, b))

@@ -28,9 +28,9 @@ PHASES = ["table", "item_header", "survivor_compaction", "chunk_loads_pixels_Bst
           "loop_wait_barrier", "elimination_step", "flush", "exit"]
 
 
-def census(synth, cfgname, B, calls, dev):
+def census(synth, cfgname, B, calls, dev, estimate=0):
     cfg = dict(synth.CONFIGS[cfgname])
-    hn = cfg["hn"]
+    hn = estimate if estimate else cfg["hn"]
     d = synth.make_batch(B=B, **{k: v for k, v in cfg.items() if k not in ("B", "hn")}, device=dev)
     grid = 48 * 256 + 64
     dbg = torch.zeros(16 * grid, dtype=torch.int64, device=dev)
@@ -38,7 +38,11 @@ def census(synth, cfgname, B, calls, dev):
     keep = []
     for _ in range(calls):
         dbg.zero_()
-        capi.v3(d["mask"], d["vertex"], hn, 0.99, max_num=cfg.get("max_num", 30000), seed=5, count_kernel=3)
+        if estimate:    # estimate_voting_distribution_with_mean, no count output, its pass forced into stages (PVV_COUNT_STAGED_ESTIMATE)
+            capi.estimate(d["mask"], d["vertex"], d["kpt_2d"].contiguous(), hn, 0.99, max_num=cfg.get("max_num", 30000), seed=5, count_kernel=4,
+                          want_counts=False)
+        else:
+            capi.v3(d["mask"], d["vertex"], hn, 0.99, max_num=cfg.get("max_num", 30000), seed=5, count_kernel=3)
         torch.cuda.synchronize()
         keep.append(dbg.cpu().view(-1, 16).clone())
     rows = []
@@ -74,7 +78,7 @@ def census(synth, cfgname, B, calls, dev):
                      "share": [float(cyc[:, i].sum() / tot) for i in range(10)]})
     med = lambda k: sorted(r[k] for r in rows)[len(rows) // 2]                       # noqa: E731
     medv = lambda k, i: sorted(r[k][i] for r in rows)[len(rows) // 2]               # noqa: E731
-    out = {"case": "%s_B%d" % (cfgname, B), "hn": hn, "calls": len(rows)}
+    out = {"case": "%s_B%d%s" % (cfgname, B, "_estimate" if estimate else ""), "hn": hn, "calls": len(rows)}
     for k in ("blocks_launched", "blocks_with_items", "items", "chunks", "survivors_per_chunk_mean", "mfma_tiles_wave0_per_chunk_mean",
               "span_us", "life_us_median", "life_us_max", "entry_us_max", "shader_clock_ghz"):
         out[k] = round(med(k), 3)
@@ -92,6 +96,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", default="cfg3:64,cfg5:16")
     ap.add_argument("--calls", type=int, default=15)
+    ap.add_argument("--estimate", type=int, default=0, help="N > 0: the census of the ESTIMATE's staged pass with N hypotheses instead of v3's")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     synth = variant_time._synth()
@@ -101,7 +106,7 @@ def main():
            "cases": []}
     for c in a.cases.split(","):
         cfgname, b = c.split(":")
-        r = census(synth, cfgname, int(b), a.calls, dev)
+        r = census(synth, cfgname, int(b), a.calls, dev, a.estimate)
         res["cases"].append(r)
         print(json.dumps(r), flush=True)
     if a.out:
