@@ -143,6 +143,8 @@ struct StageArgs {
                           // (zeroed by k_compact_hyp; count_filter_runs.hpp)
     int sub_tenth;        // 1: the caller is estimate_voting_distribution_with_mean, which weighs every hypothesis whose ratio is
                           // within 0.1 of the best (P:262-264): the elimination bound is lowered accordingly (stage_bound)
+    const float2 *mean;   // k_count_filter_runs, the estimate: [B,K] the keypoints the covariance is taken about, or nullptr.  Not
+                          // nullptr: a run walks its chunks NEAREST (in y) to the keypoint first -- see the chunk order there
     int hstride;          // row length of hyps / counts / miss when the hn hypotheses counted are a column range of longer rows (the
                           // fused un_pnp call counts its 512 + 4096 hypotheses as two passes over one compaction); 0: hn
 #ifdef PVV_STAMPS

@@ -278,9 +278,9 @@ StageHint *stage_hint_locked(hipStream_t st, bool allocate)
     return g->ratio ? g : nullptr;
 }
 
-bool hint_same_shape(const StageHint *g, const pvv_problem *p)
+bool hint_same_shape(const StageHint *g, const pvv_problem *p, bool any_hn = false)
 {
-    return g->shape[1] == p->H && g->shape[2] == p->W && g->shape[3] == p->K && g->shape[4] == p->hn;
+    return g->shape[1] == p->H && g->shape[2] == p->W && g->shape[3] == p->K && (any_hn || g->shape[4] == p->hn);
 }
 
 // A v3 call is about to leave its winners' ratios in the device's slot: record whose they are and hand out the array.
@@ -303,14 +303,15 @@ float *stage_hint_claim(const pvv_problem *p, hipStream_t st)
 }
 
 // mean winner ratio of the images the last calls OF THIS SHAPE reported (< 0: no data) and the largest tn among them
-float stage_hint_mean(const pvv_problem *p, hipStream_t st, float *max_tn = nullptr, double *sum_tn = nullptr)
+// (any_hn: the hint of a v3 call on the same fields with ANOTHER hypothesis count counts too -- the estimate's question)
+float stage_hint_mean(const pvv_problem *p, hipStream_t st, float *max_tn = nullptr, double *sum_tn = nullptr, bool any_hn = false)
 {
     if (max_tn) *max_tn = -1.f;
     if (sum_tn) *sum_tn = -1.0;
     std::lock_guard<std::mutex> lock(g_hint_mu);
     StageHint *g = stage_hint_locked(st, false);
     if (!g || g->n <= 0) return -1.f;
-    if (p && !hint_same_shape(g, p)) return -1.f;
+    if (p && !hint_same_shape(g, p, any_hn)) return -1.f;
     double sum = 0, stn = 0;
     int cnt = 0;
     float mt = 0.f;
@@ -466,6 +467,7 @@ struct StagedLaunch {
     int per_cu_first, per_cu_filter, target_first, target_filter;
     int sub_tenth;       // 1: the estimate's bound (StageArgs.sub_tenth)
     int col0, hstride, lead_set;   // CountCols (0, 0, 0: whole rows of p->hn hypotheses)
+    const float *mean;
 };
 
 // the three launches of a staged count pass for one chunk schedule (FIRST = the residues mod 8 the first launch counts)
@@ -488,6 +490,7 @@ int launch_staged(const StagedLaunch &a)
     sa.miss = (int *)(ws + L.miss) + a.col0;
     sa.sub_tenth = a.sub_tenth;
     sa.hstride = a.hstride;
+    sa.mean = (a.sub_tenth && tuning_int("PVV_PROX", 1) != 0) ? (const float2 *)a.mean : nullptr;
 #ifdef PVV_STAMPS
     sa.dbg = tuning_ptr("PVV_DBG_PTR_FILTER");                    // phase census of the second launch (tools/census_filter.py)
 #endif
@@ -536,6 +539,7 @@ struct CountCols {
     int col0 = 0;        // first column
     int hstride = 0;     // row length (0: p->hn, whole rows)
     int lead_set = 0;    // which of the workspace's two sets of leader words the pass uses
+    const float *mean = nullptr;   // the estimate in stages: [B,K,2] keypoints (device) its second launch orders the chunks by, or nullptr
 };
 
 int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream_t st, int staged /*0: full pass, 1: v3 in stages, 2: the estimate in stages*/,
@@ -598,8 +602,10 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     sl.p = p; sl.ws = ws; sl.L = &L; sl.st = st; sl.fc = fc; sl.dbg = dbg;
     sl.per_cu_first = per_cu_first; sl.per_cu_filter = per_cu_filter; sl.target_first = target_first; sl.target_filter = target_filter;
     sl.sub_tenth = staged == 2 ? 1 : 0;
-    sl.col0 = cc.col0; sl.hstride = cc.hstride; sl.lead_set = cc.lead_set;
-    const bool eighth = tuning_int("PVV_STAGE_EIGHTH", (p->count_kernel == PVV_COUNT_AUTO ? stage_work(p, st) : stage_proxy_work(p)) >= 2.26e10 * 4.757 ? 1 : 0) != 0;
+    sl.col0 = cc.col0; sl.hstride = cc.hstride; sl.lead_set = cc.lead_set; sl.mean = cc.mean;
+    // (the ESTIMATE keeps the quarter at every size: its second launch walks the chunks nearest to the keypoint first, and an
+    // eighth is 1.5 % slower at B = 64, 2-3 % at B = 6-8, +-1 % on config 5 -- profiles/r05_experiments.txt (15))
+    const bool eighth = tuning_int("PVV_STAGE_EIGHTH", (staged != 2 && (p->count_kernel == PVV_COUNT_AUTO ? stage_work(p, st) : stage_proxy_work(p)) >= 2.26e10 * 4.757) ? 1 : 0) != 0;
     return eighth ? launch_staged<kStageFirstEighth>(sl) : launch_staged<kStageFirst>(sl);
 }
 
@@ -634,8 +640,24 @@ CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
 // only from kEstStageMinWork = 2e11 evaluations-equivalent on (B*K*hn*H*W: 18 LINEMOD frames at 4096 hypotheses, 540x720 / K = 17 /
 // 2048 at B = 16) and >= 1024 hypotheses; PVV_COUNT_STAGED_ESTIMATE forces it at every size (the tests' cross-check of the
 // bound), PVV_COUNT_FULL forbids it, and PVV_COUNT_STAGED means v3 alone.
+// With the chunks of a run walked NEAREST to the keypoint first (count_filter_runs.hpp: a hypothesis' misses sit around the
+// keypoint) the staged pass is another 5-7 % faster and wins from 6 LINEMOD frames on: staged / full on clean fields 0.93 at
+// B = 6, 0.94 at 8, 0.91 at 12, 0.85 at 24, 0.83-0.85 at 48-64 (1.10 at B = 4); 540x720 / K = 17 / 2048 hypotheses 0.80 at B = 4, 0.76 at
+// 8; 9.5 % outlier pixels 0.95-0.96 at 8-16; 30 % outliers 1.00 / 0.99 / 0.88 at 8 / 16 / 64; structured errors 1.05 / 1.07 / 1.00 /
+// 0.96 at 8 / 16 / 24 / 64 (profiles/r05_experiments.txt (15)).  What separates those fields is what the v3 call that precedes every
+// estimate (resnet18.py:71-72) has just reported: the winners' ratios and the images' tn -- the stage hint of the shape (H, W, K),
+// whatever its hn.  With a hint the bound is on the REAL work K * hn * sum(tn) / 0.02: 6e10 for ratios >= 0.95, 9e10 from 0.85 on,
+// kEstStageMinWork below; without one the proxy against kEstStageMinWork, as before.
 constexpr double kEstStageMinWork = 2e11;
-bool est_stage_auto(const pvv_problem *p) { return p->hn >= 1024 && stage_proxy_work(p) >= kEstStageMinWork; }
+bool est_stage_auto(const pvv_problem *p, hipStream_t st)
+{
+    if (p->hn < 1024) return false;
+    double sum_tn = -1.0;
+    const float rho = stage_hint_mean(p, st, nullptr, &sum_tn, /*any_hn=*/true);
+    if (rho < 0.f || sum_tn < 0.0) return stage_proxy_work(p) >= kEstStageMinWork;
+    const double work = (double)p->K * p->hn * sum_tn / kStageProxyFg;
+    return work >= (rho >= 0.95f ? 6e10 : (rho >= 0.85f ? 9e10 : kEstStageMinWork));
+}
 //
 // kind: 0 = the pass must deliver every count (the estimate when its counts are an output, the fused un_pnp pass);
 //       1 = ransac_voting_layer_v3 proper, which keeps the arg-max and may count in stages;
@@ -646,7 +668,7 @@ int decide_staged(const pvv_problem *p, const Layout &L, hipStream_t st, int kin
 {
     if (!may_stage(p) || L.lead == 0) return 0;
     if (kind == 1 && stage_hint_allows(p, st)) return 1;
-    if (kind == 2 && (p->count_kernel == PVV_COUNT_STAGED_ESTIMATE || (p->count_kernel == PVV_COUNT_AUTO && est_stage_auto(p)))) return 2;
+    if (kind == 2 && (p->count_kernel == PVV_COUNT_STAGED_ESTIMATE || (p->count_kernel == PVV_COUNT_AUTO && est_stage_auto(p, st)))) return 2;
     return 0;
 }
 
@@ -882,7 +904,8 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
               const int32_t *d_idxs, const float *d_selection, char *ws, const Layout &L,
               hipStream_t st, int32_t *d_tn, const float *d_seg = nullptr, int64_t *d_mask_out = nullptr,
               const int32_t *d_idxs2 = nullptr, int hn_first = -1, uint32_t stream_first = 1u, uint32_t stream_rest = 3u,
-              int stage_kind = 0 /*decide_staged's kind*/, const CountPlan *plan = nullptr)
+              int stage_kind = 0 /*decide_staged's kind*/, const CountPlan *plan = nullptr,
+              const float *d_mean = nullptr /*the estimate: the keypoints its staged pass orders the chunks by*/)
 {
     if ((p->flags & PVV_FLAG_DEVICE_RNG) && (d_idxs || d_idxs2 || d_selection))
         return fail(PVV_E_ARG, "PVV_FLAG_DEVICE_RNG promises d_idxs = d_idxs_est = d_selection = NULL");
@@ -936,7 +959,9 @@ int run_front(const pvv_problem *p, int mode, const void *d_mask, const float *d
         }
         if (le) return le;
     }
-    if (int e = plan ? launch_count_any(plan->p, L, ws, st, plan->staged, plan->cols) : launch_count_any(p, L, ws, st, staged)) return e;
+    CountCols whole;
+    whole.mean = d_mean;
+    if (int e = plan ? launch_count_any(plan->p, L, ws, st, plan->staged, plan->cols) : launch_count_any(p, L, ws, st, staged, whole)) return e;
     if (int e = sj.finish()) return e;
     return mark(p, PVV_MARK_COUNT, st);
 }
@@ -1108,7 +1133,7 @@ PVV_EXPORT int pvv_estimate_voting_distribution(const pvv_problem *p, const void
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)d_workspace;
     // the counts are an output (d_counts): every one of them is needed; otherwise the pass may drop what cannot carry weight
-    if (int e = run_front(p, 1, d_mask, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, nullptr, nullptr, nullptr, -1, 3u, 3u, d_counts ? 0 : 2)) return e;
+    if (int e = run_front(p, 1, d_mask, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, nullptr, nullptr, nullptr, -1, 3u, 3u, d_counts ? 0 : 2, nullptr, d_mean)) return e;
     hipLaunchKernelGGL(k_covariance, dim3(p->K, p->B), dim3(kBlock), 0, st,
                        (const int *)(ws + L.tn), (const float2 *)(ws + L.hyps),
                        (const int *)(ws + L.counts), (const float2 *)d_mean, d_cov, (float2 *)d_hyp,
@@ -1121,7 +1146,7 @@ PVV_EXPORT int pvv_estimate_counts_in_stages(const pvv_problem *p)
 {
     if (int e = validate(p)) return e < 0 ? e : -e;
     if (!may_stage(p)) return 0;
-    return (p->count_kernel == PVV_COUNT_STAGED_ESTIMATE || (p->count_kernel == PVV_COUNT_AUTO && est_stage_auto(p))) ? 1 : 0;
+    return (p->count_kernel == PVV_COUNT_STAGED_ESTIMATE || (p->count_kernel == PVV_COUNT_AUTO && est_stage_auto(p, nullptr))) ? 1 : 0;
 }
 
 // resnet18.py:65-72 with cfg.test.un_pnp as ONE pass (see the header): the row of every (image, keypoint) holds the hn
@@ -1180,7 +1205,7 @@ PVV_EXPORT int pvv_decode_keypoint_un_pnp(const pvv_problem *p, int32_t hn_est, 
             return e;
         if (int e = finish_v3(p, L, ws, d_kpt, d_win_counts, st, q.hn)) return e;
         CountCols ec;
-        ec.col0 = p->hn; ec.hstride = q.hn; ec.lead_set = 1;
+        ec.col0 = p->hn; ec.hstride = q.hn; ec.lead_set = 1; ec.mean = d_kpt;
         if (int e = launch_count_any(&pe, L, ws, st, est_staged, ec)) return e;
     } else {
         if (int e = run_front(&q, 0, nullptr, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, d_seg, d_mask_out, d_idxs_est,

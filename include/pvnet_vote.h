@@ -293,8 +293,11 @@ int pvv_estimate_voting_distribution(const pvv_problem *p, const void *d_mask,
  * workspace: pvv_workspace_bytes_un_pnp(p, hn_est). */
 size_t pvv_workspace_bytes_un_pnp(const pvv_problem *p, int32_t hn_est);
 
-/* ABI v8: 1 when pvv_estimate_voting_distribution would count this problem IN STAGES (d_counts == NULL; PVV_COUNT_AUTO from
- * ~2e11 evaluations-equivalent on, or PVV_COUNT_STAGED_ESTIMATE), 0 when it counts in full, < 0 for an invalid problem.
+/* ABI v8: 1 when pvv_estimate_voting_distribution would count this problem IN STAGES (d_counts == NULL; PVV_COUNT_STAGED_ESTIMATE,
+ * or PVV_COUNT_AUTO: from ~2e11 evaluations-equivalent B*K*hn*H*W on -- 18 LINEMOD frames at 4096 hypotheses -- or, once a v3 call
+ * on fields of the same H, W, K has reported its winners' ratios and tn on the current device (the stage hint; resnet18.py:71-72
+ * runs v3 right before every estimate), from 6e10 of REAL work K*hn*sum(tn)/0.02 on clean fields (6 LINEMOD frames), 9e10 for
+ * ratios >= 0.85), 0 when it counts in full, < 0 for an invalid problem.
  * pvv_decode_keypoint_un_pnp applies the same rule to its estimate columns (see there), so a host no longer has to choose
  * between the fused call and the two calls; the query stays for hosts that want to know which pass will run. */
 int pvv_estimate_counts_in_stages(const pvv_problem *p);

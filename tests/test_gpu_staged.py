@@ -413,10 +413,13 @@ def test_estimate_counted_in_stages_equals_the_full_pass(synth, pkg, gpu, B, H, 
 def test_auto_counts_a_large_estimate_in_stages_and_equals_the_full_pass(synth, pkg, gpu):
     """Round 5: with the second launch at five blocks per CU the staged estimate wins from ~18 LINEMOD frames on, and AUTO takes it
     (pvv_estimate_counts_in_stages).  24 frames, 4096 hypotheses: covariances and PnP weights equal the full pass bit for bit, the
-    stage marks show that the pass really ran in stages; 8 frames stay with the full pass; decode_keypoint(un_pnp=True) is the one
-    fused call at every size (which then counts its rows as two passes, see the next test) and equals the two separate calls."""
+    stage marks show that the pass really ran in stages; 8 frames stay with the full pass UNTIL a v3 call on the same fields has
+    reported clean winners (the stage hint of the shape, whatever its hn: with the nearest-first chunk order the staged pass wins
+    from 6 clean frames on); decode_keypoint(un_pnp=True) is the one fused call at every size (which then counts its rows as two
+    passes, see the next test) and equals the two separate calls."""
     from clean_pvnet_amd import decode_keypoint
     from clean_pvnet_amd import ransac_voting as ext
+    ext.shutdown()                                                       # forget the stage hints other tests left on the device
     assert ext.estimate_counts_in_stages(24, 480, 640, 9, 4096) and not ext.estimate_counts_in_stages(8, 480, 640, 9, 4096)
     d = synth.make_batch(**{**synth.CONFIGS["cfg3"], "B": 24}, device=gpu)
     m, v = d["mask"], d["vertex"]
@@ -427,7 +430,17 @@ def test_auto_counts_a_large_estimate_in_stages_and_equals_the_full_pass(synth, 
     ms = ext.stage_ms_in_pipeline([m], [v], 4096, 0.99, 5, 30000, 3, 8, ext.COUNT_AUTO, True, True)
     assert all(r[5] > 0 for r in ms)                                   # the first-launch mark was recorded: staged
     ms8 = ext.stage_ms_in_pipeline([m[:8]], [v[:8]], 4096, 0.99, 5, 30000, 3, 8, ext.COUNT_AUTO, True, True)
-    assert all(r[5] < 0 for r in ms8)                                  # 8 frames: the full pass
+    assert all(r[5] < 0 for r in ms8)                                  # 8 frames, no hint: the full pass
+    for _ in range(2):                                                 # v3 on the same (clean) fields leaves the hint: ratios ~0.995, tn
+        ext.ransac_voting_v3(m[:8], v[:8], 512, 0.99, 5, 30000, None, None, 1, ext.SINGULAR_REFERENCE)
+        torch.cuda.synchronize()
+    assert ext.estimate_counts_in_stages(8, 480, 640, 9, 4096)
+    full8 = ext.estimate_voting_distribution(m[:8], v[:8], mean[:8].contiguous(), 4096, 0.99, 5, 30000, None, None, 9, False, 0, ext.COUNT_FULL)
+    auto8 = ext.estimate_voting_distribution(m[:8], v[:8], mean[:8].contiguous(), 4096, 0.99, 5, 30000, None, None, 9, False, 0, ext.COUNT_AUTO)
+    assert torch.equal(auto8[0], full8[0]) and torch.equal(auto8[4], full8[4])
+    ms8 = ext.stage_ms_in_pipeline([m[:8]], [v[:8]], 4096, 0.99, 5, 30000, 3, 8, ext.COUNT_AUTO, True, True)
+    assert all(r[5] > 0 for r in ms8)                                  # ... now in stages
+    assert not ext.estimate_counts_in_stages(3, 480, 640, 9, 4096)     # (3 frames: 3.4e10 of work, below every bound)
     x = torch.empty(24, 2 + 18, 480, 640, device=gpu)
     x[:, 0] = 3.0 * (m == 0)
     x[:, 1] = 3.0 * (m != 0)

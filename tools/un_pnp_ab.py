@@ -1,5 +1,12 @@
+#!/usr/bin/env python
+"""The un_pnp path three ways in one process, whole calls on two rotating batches of config 3 (ms per step, two rounds each):
+the one fused call as the library runs it (pvv_decode_keypoint_un_pnp; rows counted as two passes where the estimate stages),
+the same call with its single full count pass forced (PVV_COUNT_FULL), and the reference's two calls on the int64 mask.
+
+    BS=64,32,24 python tools/un_pnp_ab.py
+"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import lib
@@ -36,4 +43,4 @@ for B in [int(x) for x in os.environ.get("BS", "64").split(",")]:
     for rep in range(2):
         for name, f in (("fused", fused), ("fused_full", fused_full), ("two_calls", two)):
             r.setdefault(name, []).append(round(timeit(f), 4))
-    print("B", B, "defer", os.environ.get("PVV_HYP_DEFER", "default"), r, flush=True)
+    print("B", B, r, flush=True)
