@@ -824,7 +824,9 @@ def un_pnp_leg(data, out, ext, ransac_voting_layer_v3, estimate_voting_distribut
     el, _p, _o = run(one_pass, 2, n)
     res.update({"un_pnp_fused_one_pass_images_per_s": round(B * n / el, 1), "un_pnp_fused_one_pass_ms_per_step": round(1e3 * el / n, 4)})
     del x
-    sta = ext.stage_ms_in_pipeline([mask], [vertex], 4096, thresh, 5, 30000, 3, 10, ext.COUNT_AUTO, False, True)[4:]
+    # (about the keypoints v3 finds: the staged pass walks the chunks nearest to them first)
+    kp = ransac_voting_layer_v3(mask, vertex, hn, inlier_thresh=thresh).contiguous()
+    sta = ext.stage_ms_in_pipeline([mask], [vertex], 4096, thresh, 5, 30000, 3, 10, ext.COUNT_AUTO, False, True, [], [kp])[4:]
     res["estimate_4096_count_pass_as_auto_runs_it_ms"] = round(sorted(r[2] for r in sta)[len(sta) // 2], 4)
     res["estimate_4096_counted_in_stages_by_auto"] = two
     st = ext.stage_ms_in_pipeline([mask], [vertex], 4096, thresh, 5, 30000, 3, 10, ext.COUNT_FULL, False, True)[4:]

@@ -597,7 +597,11 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     // below through two leaders (k_lead), then the rest only for the hypotheses that can still reach that bound.  The first
     // stage is a QUARTER of the chunks, or an EIGHTH when the problem is so large that the second launch's runs are long
     // (measured, one-process A/B of whole calls: -5 % at config 3 / B = 96, -4 % at B = 128, -9 % on config 5 / B = 16, -5 % at its
-    // B = 8; +2.5 % at config 3 / B = 64: log2(work / 2.26e10) >= 2.25)
+    // B = 8; +2.5 % at config 3 / B = 64, +4.8 % on config 5 / B = 4 with unequal keypoints).  "Long" is a property of the RUNS, not of
+    // the hypothesis count: x = K * sum(tn) / 512 chunks per block slot of the second launch -- 5.4 at config 3 / B = 64, 8.1 at 96,
+    // 6.2 / 3.1 on config 5 at B = 8 / 4 -- and the eighth pays from x = 5.8 on.  (Until round 5 the bound was on the work
+    // K * hn * sum(tn), which told the same for 512 hypotheses and sent config 5's 2048 to the eighth from B = 2 on: the one case
+    // of tools/auto_regret.py above 1.03.)
     StagedLaunch sl;
     sl.p = p; sl.ws = ws; sl.L = &L; sl.st = st; sl.fc = fc; sl.dbg = dbg;
     sl.per_cu_first = per_cu_first; sl.per_cu_filter = per_cu_filter; sl.target_first = target_first; sl.target_filter = target_filter;
@@ -605,7 +609,9 @@ int launch_count_bf16(const pvv_problem *p, const Layout &L, char *ws, hipStream
     sl.col0 = cc.col0; sl.hstride = cc.hstride; sl.lead_set = cc.lead_set; sl.mean = cc.mean;
     // (the ESTIMATE keeps the quarter at every size: its second launch walks the chunks nearest to the keypoint first, and an
     // eighth is 1.5 % slower at B = 64, 2-3 % at B = 6-8, +-1 % on config 5 -- profiles/r05_experiments.txt (15))
-    const bool eighth = tuning_int("PVV_STAGE_EIGHTH", (staged != 2 && (p->count_kernel == PVV_COUNT_AUTO ? stage_work(p, st) : stage_proxy_work(p)) >= 2.26e10 * 4.757) ? 1 : 0) != 0;
+    const double sum_tn = (p->count_kernel == PVV_COUNT_AUTO ? stage_work(p, st) : stage_proxy_work(p)) * kStageProxyFg / ((double)p->K * p->hn);
+    const double chunks_per_slot = (double)p->K * sum_tn / (4.0 * kBfPixPerWave) / (5.0 * num_cus());
+    const bool eighth = tuning_int("PVV_STAGE_EIGHTH", (staged != 2 && chunks_per_slot >= 5.8) ? 1 : 0) != 0;
     return eighth ? launch_staged<kStageFirstEighth>(sl) : launch_staged<kStageFirst>(sl);
 }
 

@@ -455,8 +455,12 @@ std::vector<double> count_kernel_ms_in_pipeline(std::vector<at::Tensor> masks, s
 std::vector<std::vector<double>> stage_ms_in_pipeline(std::vector<at::Tensor> masks, std::vector<at::Tensor> vertices,
                                                       int64_t round_hyp_num, double inlier_thresh, int64_t min_num,
                                                       int64_t max_num, int64_t seed, int64_t reps, int64_t count_kernel,
-                                                      bool inner_marks, bool estimate, std::vector<at::Tensor> segs)
+                                                      bool inner_marks, bool estimate, std::vector<at::Tensor> segs,
+                                                      std::vector<at::Tensor> means)
 {
+    // means (optional, with estimate: one [b,vn,2] float32 tensor per vertex field): the keypoints the estimate is taken about --
+    // its staged pass orders the chunks by them; empty: zeros (row-major order, the timing of rounds 2-4)
+    TORCH_CHECK(means.empty() || (estimate && means.size() == vertices.size()), "means: one per vertex field, estimate only");
     // segs (optional, one [b,c,h,w] float32 tensor per vertex field): time pvv_decode_keypoint_v3 -- the class argmax fused
     // into the mask scan, the int64 mask written out -- instead of pvv_ransac_voting_v3; `masks` may then be empty
     const bool fused = !segs.empty();
@@ -495,7 +499,13 @@ std::vector<std::vector<double>> stage_ms_in_pipeline(std::vector<at::Tensor> ma
         at::Tensor ws = make_workspace(p, vertex);
         auto out = at::empty({p.B, p.K, 2}, vertex.options());
         if (estimate) {      // estimate_voting_distribution_with_mean with round_hyp_num hypotheses in total (mean = zeros: timing only)
-            out.zero_();
+            if (means.empty()) out.zero_();
+            else {
+                const at::Tensor &mn = means[r % means.size()];
+                check_dev(mn, "mean", at::kFloat);
+                TORCH_CHECK(mn.dim() == 3 && mn.size(0) == p.B && mn.size(1) == p.K && mn.size(2) == 2, "mean must be [b,vn,2]");
+                out.copy_(mn);
+            }
             auto cov = at::empty({p.B, p.K, 2, 2}, vertex.options());
             ok(pvv_estimate_voting_distribution(&p, mask.data_ptr(), vertex.data_ptr<float>(), nullptr, nullptr, out.data_ptr<float>(),
                                                 ws.data_ptr(), (size_t)ws.numel(), cov.data_ptr<float>(), nullptr, nullptr, nullptr,
@@ -633,7 +643,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           "per-stage durations inside full v3 calls, HIP events at the stage boundaries (profiling aid)", py::arg("masks"),
           py::arg("vertices"), py::arg("round_hyp_num"), py::arg("inlier_thresh"), py::arg("min_num"), py::arg("max_num"),
           py::arg("seed"), py::arg("reps"), py::arg("count_kernel") = 0, py::arg("inner_marks") = true, py::arg("estimate") = false,
-          py::arg("segs") = std::vector<at::Tensor>());
+          py::arg("segs") = std::vector<at::Tensor>(), py::arg("means") = std::vector<at::Tensor>());
     m.def("stage_hint", [](at::Tensor mask, at::Tensor vertex, int64_t hn) {
               pvv_problem p = make_problem(mask, vertex, hn, 0.99, 5, 30000, 0, 0);
               float mean = -1.f, thr = -1.f;

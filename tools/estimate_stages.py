@@ -28,7 +28,7 @@ d = synth.make_batch(B=B, **gen, device=dev)
 m, v = d["mask"], d["vertex"]
 med = lambda x: sorted(x)[len(x) // 2]  # noqa: E731
 for name, mode in (("full", ext.COUNT_FULL), ("staged", ext.COUNT_STAGED_ESTIMATE)):
-    ms = ext.stage_ms_in_pipeline([m], [v], 4096, 0.99, 5, 30000, 3, 12, mode, True, True)[4:]
+    ms = ext.stage_ms_in_pipeline([m], [v], 4096, 0.99, 5, 30000, 3, 12, mode, True, True, [], [d["kpt_2d"].contiguous()])[4:]
     print(name, "B=%d" % B, "eighth=" + os.environ.get("PVV_STAGE_EIGHTH", "default"), "run_r=" + os.environ.get("PVV_RUN_R", "default"),
           [round(med(c), 4) for c in zip(*ms)], flush=True)
 if os.environ.get("SURV"):
