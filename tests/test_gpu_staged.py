@@ -491,3 +491,75 @@ def test_fused_un_pnp_rows_counted_as_two_passes_equal_the_one_full_pass(synth, 
         i1 = torch.randint(0, tn_min, (B, hn_est, K, 2), generator=g, dtype=torch.int32).to(gpu)
         a, b = run(ext.COUNT_FULL, i0, i1), run(ext.COUNT_STAGED_ESTIMATE, i0, i1)
         assert all(torch.equal(a_, b_) for a_, b_ in zip(a, b))
+
+
+@pytest.mark.parametrize("what", ["many_chunks", "nan_mean", "far_mean", "one_image", "mean_inside_each_band"])
+def test_estimate_chunk_order_edge_cases(synth, pkg, gpu, what):
+    """The estimate's second launch walks a run's chunks nearest (in y) to the keypoint first (count_filter_runs.hpp) -- any order
+    counts the same pairs, so covariances and weights must equal the full pass bit for bit whatever the keypoints are: more than
+    64 remaining chunks per image (the order falls back to row-major), NaN / infinite keypoints, keypoints far outside the image,
+    a single image (many short runs per keypoint), and keypoints placed inside every band of the mask in turn."""
+    from clean_pvnet_amd import ransac_voting as ext
+    if what == "many_chunks":
+        B, H, W, K, hn, fg, max_num = 2, 512, 512, 3, 1024, 0.3, 200000          # ~78 000 rows per image: 153 chunks, 115 remaining
+    elif what == "one_image":
+        B, H, W, K, hn, fg, max_num = 1, 480, 640, 9, 4096, 0.05, 30000
+    else:
+        B, H, W, K, hn, fg, max_num = 3, 480, 640, 5, 2048, 0.03, 30000
+    d = synth.make_batch(B=B, H=H, W=W, K=K, fg=fg, sigma=0.05, outlier=0.05, seed=7300 + len(what), device=gpu)
+    m, v = d["mask"], d["vertex"]
+    means = [(d["kpt_2d"] + 0.25).contiguous()]
+    if what == "nan_mean":
+        mn = means[0].clone()
+        mn[0, 0] = float("nan")
+        mn[1, 1, 1] = float("inf")
+        mn[2, 2, 0] = float("-inf")
+        means = [mn]
+    elif what == "far_mean":
+        means = [means[0] + 1e7, means[0] * 0 - 5e4]
+    elif what == "mean_inside_each_band":
+        ys = torch.nonzero(m[0])[:, 0].float()
+        means = []
+        for q in (0.0, 0.1, 0.35, 0.5, 0.8, 1.0):
+            mn = d["kpt_2d"].clone()
+            mn[..., 1] = ys.min() + q * (ys.max() - ys.min())
+            means.append(mn.contiguous())
+    for mean in means:
+        full = ext.estimate_voting_distribution(m, v, mean, hn, 0.99, 5, max_num, None, None, 9, False, 0, ext.COUNT_FULL)
+        if what == "many_chunks":
+            assert int(full[3].min().item()) > 64 * 512 * 8 // 6                 # enough rows for > 64 remaining chunks
+        for rep in range(2):
+            st = ext.estimate_voting_distribution(m, v, mean, hn, 0.99, 5, max_num, None, None, 9, False, 0, ext.COUNT_STAGED_ESTIMATE)
+            same = lambda a_, b_: torch.equal(a_, b_) or bool(((a_ == b_) | (a_.isnan() & b_.isnan())).all())   # noqa: E731
+            assert same(st[0], full[0]) and same(st[4], full[4]) and torch.equal(st[3], full[3]), (what, rep)
+
+
+def test_staged_estimate_and_fused_two_pass_on_random_shapes(synth, pkg, gpu):
+    """Twelve seeded random problems (image size, keypoints, hypothesis counts that are no multiples of 32, foreground, outliers):
+    the estimate counted in stages and the fused un_pnp call with its rows counted as two passes against their full passes, bit
+    for bit."""
+    from clean_pvnet_amd import ransac_voting as ext
+    rng = np.random.default_rng(20260926)
+    for case in range(12):
+        B = int(rng.integers(1, 7))
+        H, W = int(rng.integers(96, 400)), int(rng.integers(96, 400))
+        K = int(rng.integers(1, 10))
+        hn, hn_est = int(rng.integers(33, 600)), int(rng.integers(130, 2500))
+        fg = float(rng.uniform(0.05, 0.5))
+        outlier = float(rng.choice([0.0, 0.05, 0.3]))
+        d = synth.make_batch(B=B, H=H, W=W, K=K, fg=fg, sigma=0.05, outlier=outlier, seed=8800 + case, device=gpu)
+        m, v = d["mask"], d["vertex"]
+        tag = (case, B, H, W, K, hn, hn_est, round(fg, 2), outlier)
+        mean = (d["kpt_2d"] + float(rng.uniform(-3, 3))).contiguous()
+        full = ext.estimate_voting_distribution(m, v, mean, hn_est, 0.99, 5, 30000, None, None, case, False, 0, ext.COUNT_FULL)
+        st = ext.estimate_voting_distribution(m, v, mean, hn_est, 0.99, 5, 30000, None, None, case, False, 0, ext.COUNT_STAGED_ESTIMATE)
+        assert torch.equal(st[0], full[0]) and torch.equal(st[4], full[4]), tag
+        x = torch.empty(B, 2 + 2 * K, H, W, device=gpu)
+        x[:, 0] = 3.0 * (m == 0)
+        x[:, 1] = 3.0 * (m != 0)
+        x[:, 2:] = v.permute(0, 3, 4, 1, 2).reshape(B, 2 * K, H, W)
+        seg, vtx = x[:, :2], x[:, 2:].permute(0, 2, 3, 1).view(B, H, W, K, 2)
+        a = ext.decode_keypoint_un_pnp(seg, vtx, hn, hn_est, 0.99, 5, 30000, None, None, None, case, ext.SINGULAR_REFERENCE, 0, ext.COUNT_FULL)
+        b = ext.decode_keypoint_un_pnp(seg, vtx, hn, hn_est, 0.99, 5, 30000, None, None, None, case, ext.SINGULAR_REFERENCE, 0, ext.COUNT_STAGED_ESTIMATE)
+        for a_, b_, nm in zip(a, b, ("keypoints", "mask", "covariances", "weights", "winner counts", "tn")):
+            assert torch.equal(a_, b_), (nm,) + tag
