@@ -26,7 +26,7 @@ def decode_keypoint(output, un_pnp=False, *, idxs=None, selection=None, singular
     ``estimate_voting_distribution_with_mean`` (resnet18.py:71-72) as ONE call -- one mask scan, one compaction, one
     hypothesis launch for the 512 + 4096 hypotheses -- with results bit-identical to the two calls on the same draws.  Small
     batches count all 4608 hypotheses in one launch; on batches large enough for the library to count the estimate IN STAGES
-    (``pvv_estimate_counts_in_stages``, ~18 LINEMOD frames on) the same call counts the rows as two passes over the one
+    (``pvv_estimate_counts_in_stages``: from ~6 clean LINEMOD frames on once v3 has reported its winners, ~18 before) the same call counts the rows as two passes over the one
     compaction -- v3's 512 columns as the layer would, then the estimate's 4096 against its own bound -- and keeps the saved
     scan and compaction (round 5; before, the two separate calls were taken there).  ``idxs_est`` [b,4096,vn,2] injects the
     estimate's index pairs like ``idxs`` does for v3, and
