@@ -642,7 +642,7 @@ CountArgs planar_count_args(const pvv_problem *p, const Layout &L, char *ws)
 // at B = 16, 0.205 vs 0.218 at B = 8, 0.075 vs 0.053 at B = 1; 540x720, K = 17, 2048 hypotheses at B = 16: 1.438 vs 1.532; B = 24 / 48:
 // +10 % / +13 %; 2048 hypotheses at B = 64 +8.5 %, 1024 at B = 64 +2 %, at B = 16 -10 %.  On fields with STRUCTURED errors (a third
 // of the object voting for a wrong point plus keypoints of very different quality: synth wrong_region / kp_outlier) the gain shrinks
-// to +3 % at B = 64 and turns into -6 % at B = 16, -2 % at B = 8 (profiles/r05_experiments.txt (8)).  So AUTO stages an estimate
+// to +3 % at B = 64 and turns into -6 % at B = 16, -2 % at B = 8 (profiles/r05_experiments.txt (8)).  So AUTO staged an estimate
 // only from kEstStageMinWork = 2e11 evaluations-equivalent on (B*K*hn*H*W: 18 LINEMOD frames at 4096 hypotheses, 540x720 / K = 17 /
 // 2048 at B = 16) and >= 1024 hypotheses; PVV_COUNT_STAGED_ESTIMATE forces it at every size (the tests' cross-check of the
 // bound), PVV_COUNT_FULL forbids it, and PVV_COUNT_STAGED means v3 alone.
