@@ -84,15 +84,27 @@ __device__ __forceinline__ int stage_hypothesis(bf16x8 *sB, int *sCnt, int i, fl
 #ifdef PVV_STAMPS
 #define PVV_STAMP(i) do { if (dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 97 || blockIdx.x == 401)) \
     dbg[((blockIdx.x == 0 ? 0 : (blockIdx.x == 97 ? 1 : 2)) * 16) + (i)] = wall_clock64(); } while (0)
-// per-block census behind the three timelines: dbg[64 + 4*block + {0,1,2,3}] = entry time, exit time, hardware id
-// (HW_ID | XCC_ID << 32), items processed
-#define PVV_CENSUS_IN() do { if (dbg && threadIdx.x == 0) { dbg[64 + 4 * blockIdx.x] = wall_clock64(); \
-    dbg[64 + 4 * blockIdx.x + 2] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32); } } while (0)
-#define PVV_CENSUS_OUT(n) do { if (dbg && threadIdx.x == 0) { dbg[64 + 4 * blockIdx.x + 1] = wall_clock64(); \
-    dbg[64 + 4 * blockIdx.x + 3] = (n); } } while (0)
+// per-block census behind the three timelines, 16 words per block at dbg[64 + 16 * block]:
+//   [0] entry, [1] exit (wall_clock64: the 100 MHz real-time counter), [2] hardware id (HW_ID | XCC_ID << 32), [3] items processed,
+//   [4..11] SHADER cycles (s_memtime) thread 0 spent per phase -- kCensusPhases below --, [12] real-time ticks of the matrix-core
+//   loop phase, [13] matrix-core tiles wave 0 multiplied.  Shader cycles / real time = the clock the chip ran at INSIDE the phase
+//   (round 6, VERDICT r5 #1: the roofline's 2.4 GHz was never checked inside the kernels).
+enum { kCsTable = 0, kCsItemPrologue, kCsAOperands, kCsNextGroup, kCsLoop, kCsLoopWait, kCsFlush, kCsOther, kCensusPhases };
+#define PVV_CENSUS_IN() long long cs_last = 0; __shared__ long long s_cs[16]; \
+    do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 16; ++i_) s_cs[i_] = 0; s_cs[0] = wall_clock64(); \
+    s_cs[2] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32); \
+    cs_last = (long long)__builtin_readcyclecounter(); } } while (0)
+#define PVV_CS(i) do { if (threadIdx.x == 0) { const long long t_ = (long long)__builtin_readcyclecounter(); s_cs[4 + (i)] += t_ - cs_last; cs_last = t_; } } while (0)
+#define PVV_CS_RT_IN() long long cs_rt = 0; do { if (threadIdx.x == 0) cs_rt = wall_clock64(); } while (0)
+#define PVV_CS_RT_OUT(tiles) do { if (threadIdx.x == 0) { s_cs[12] += wall_clock64() - cs_rt; s_cs[13] += (tiles); } } while (0)
+#define PVV_CENSUS_OUT(n) do { if (dbg && threadIdx.x == 0) { s_cs[1] = wall_clock64(); s_cs[3] = (n); \
+    for (int i_ = 0; i_ < 16; ++i_) dbg[64 + 16 * (size_t)blockIdx.x + i_] = s_cs[i_]; } } while (0)
 #else
 #define PVV_STAMP(i) do { } while (0)
 #define PVV_CENSUS_IN() do { } while (0)
+#define PVV_CS(i) do { } while (0)
+#define PVV_CS_RT_IN() do { } while (0)
+#define PVV_CS_RT_OUT(tiles) do { } while (0)
 #define PVV_CENSUS_OUT(n) do { } while (0)
 #endif
 
@@ -270,6 +282,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     const int total = __builtin_amdgcn_readfirstlane(s_chunks) * per_chunk;
     const int col = lane & 31, kslice = lane >> 5;
     PVV_STAMP(2);
+    PVV_CS(kCsTable);
 
     // The host sizes the grid without knowing tn.  With few items (up to 7/4 of the one-generation grid = target_items)
     // only the first target_items blocks of a 15-per-CU grid take part -- one generation, a few blocks with two items,
@@ -307,6 +320,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         PVV_STAMP(3);
+        PVV_CS(kCsOther);
         ++n_items_done;
         // ---- every global load of the item is issued here, before anything waits: tn, the chunk's origin, two pixels
         //      per thread (rows beyond tn are read -- the arrays reserve cap rows -- and masked below) and the
@@ -429,6 +443,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         }
         far = __syncthreads_or(far);
         PVV_STAMP(4);
+        PVV_CS(kCsItemPrologue);
         const float C1 = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
         const float eps = fc.eps0 + fc.eps_c * C1;
         const float epsw = __builtin_fmaf(fc.beta * 1.02f, C1, eps);   // band half-width at |h'| = 0
@@ -480,6 +495,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             }
         }
         PVV_STAMP(5);
+        PVV_CS(kCsAOperands);
         const int ebase = kslice * 4;                            // this lane's pixels: ebase + e%4 + 8*(e/4)
         const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
@@ -512,6 +528,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             const int nht = FILTER ? (ns_g + 31) >> 5 : min(nt, ht0 + htpi) - ht0;
             const int nslot = FILTER ? ns_g : min(hn - ht0 * 32, nht * 32);
             PVV_STAMP(6);
+            PVV_CS(kCsNextGroup);
+            PVV_CS_RT_IN();
 
             if (__builtin_expect(far, 0)) {
                 // some hypothesis of the group is non-finite / astronomically far: exact loop (K:100-125)
@@ -621,16 +639,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 }
             }
             PVV_STAMP(7);
+            PVV_CS(kCsLoop);
+            PVV_CS_RT_OUT(nht * ntile_w);
             __syncthreads();
+            PVV_CS(kCsLoopWait);
             for (int i = threadIdx.x; i < nslot; i += kBlock) {
                 const int v = sCnt[i];
                 const int c = FILTER ? v & 0xffff : v;               // (filter: index within the group << 16 | count <= 512)
                 if (c != 0) atomicAdd(&counts[(size_t)bk * hs + ht0 * 32 + (FILTER ? v >> 16 : i)], c);
             }
             PVV_STAMP(8);
+            PVV_CS(kCsFlush);
         }
     }
     PVV_STAMP(9);
+    PVV_CS(kCsOther);
     PVV_CENSUS_OUT(n_items_done);
     (void)n_items_done;
 }

@@ -28,7 +28,7 @@ def main():
     dev = torch.device("cuda:0")
     d = synth.make_batch(B=B, **{k: v for k, v in cfg.items() if k not in ("B", "hn")}, device=dev)
     GRID = 48 * 256 + 64
-    dbg = torch.zeros(64 + 4 * GRID, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(64 + 16 * GRID, dtype=torch.int64, device=dev)
     os.environ["PVV_DBG_PTR"] = str(dbg.data_ptr())
     rows = []
     for _ in range(calls):
@@ -36,7 +36,7 @@ def main():
         capi.v3(d["mask"], d["vertex"], hn, 0.99, max_num=max_num, seed=5)
         torch.cuda.synchronize()
         rows.append(dbg.cpu().clone())
-    census = rows[-1][64:].view(-1, 4)
+    census = rows[-1][64:].view(-1, 16)[:, :4]     # (entry, exit, hardware id, items; the phase cycles behind them: tools/census_count.py)
     rows = torch.stack(rows[5:])[:, :48].reshape(-1, 3, 16)[:, :, :10].double()
     rel = (rows - rows[:, :1, :1]) / 100.0          # us relative to block 0's entry
     med = rel.median(0).values
