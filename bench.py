@@ -691,6 +691,13 @@ def main():
             "step_ms": {"median": round(pct(per_step, 0.5), 4), "p10": round(pct(per_step, 0.1), 4),
                         "p90": round(pct(per_step, 0.9), 4), "wall": round(ms_per_step, 4),
                         "how": "torch.cuda.Event pairs around every step on the launch stream (rank 0); wall = perf_counter over the timed region / steps, max over ranks"},
+            # N > 1: what a SCALE record needs to be judged without reading `extra` (round 6, VERDICT r5 #2c)
+            "multi_gpu": ({"ranks": world, "backend": backend, "rccl_ranks": (coll_ranks if backend == "nccl" else None),
+                           "collective_ranks": coll_ranks, "shard_sizes": shard_sizes,
+                           "exchange_impl": ("rccl_direct" if comm is not None else "torch_distributed"),
+                           "exchange_fallback_reason": comm_note,
+                           "oversubscribed_ranks_per_gpu": (-(-world // n_dev) if oversubscribed else None),
+                           "per_rank_count_pass_ms": per_rank_kernel_ms} if use_dist else None),
             "roofline": roofline, "roofline_dense_equivalent": dense_equivalent, "roofline_contract_count_pass": roofline_contract, "roofline_scan": roofline_scan,
             "roofline_compact": roofline_compact, "roofline_valu": roofline_valu, "cpu_baseline": cpu_baseline, "extra": extra,
         }
@@ -734,6 +741,9 @@ def predict_8gpu(config, n1_value):
         ms64, ms8 = full["event_ms_per_call_median"], part["event_ms_per_call_median"]
         return {"strong_images_per_s": round(64 / ((ms8 + exch_ms) * 1e-3), 1), "strong_speedup_vs_1gpu": round(ms64 / (ms8 + exch_ms), 2),
                 "weak_images_per_s": round(8 * 64 / ((ms64 + exch_ms) * 1e-3), 1), "weak_efficiency": round(ms64 / (ms64 + exch_ms), 3),
+                "inputs": {"shard_of_8": next(k for k in rows if k.startswith("%s_B8" % config)),
+                           "batch_of_64": next(k for k in rows if k == "%s_B64" % config or k.startswith("%s_B64_" % config)),
+                           "field": "event_ms_per_call_median", "file": "profiles/%s" % name},
                 "shard_of_8_ms_per_call": ms8, "batch_of_64_ms_per_call": ms64, "exchange_ms": round(exch_ms, 4), "exchange_ms_source": exch_src,
                 "source": "profiles/%s (one MI355X, warm caches); UNMEASURED on 8 GPUs" % name}
     except Exception as e:                                                          # never lose the bench line to this

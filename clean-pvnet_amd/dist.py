@@ -74,7 +74,8 @@ class GatherBuffer:
     def __init__(self, batch, row_shape, device, dtype=torch.float32, group=None, comm=None):
         """``comm``: a ``clean_pvnet_amd.rccl.Comm`` (or None).  With it ``gather()`` issues RCCL's all-gather directly on the
         CURRENT stream -- behind the voting kernels in stream order, no event, no second stream (rccl.py) -- instead of going
-        through ``torch.distributed`` (float32 buffers only)."""
+        through ``torch.distributed`` (float32 buffers only).  Do not interleave ``torch.distributed`` collectives of the same
+        ranks with it in rank-dependent order (two communicators on the same devices must see one global order)."""
         self.batch, self.group, self.comm = int(batch), group, comm
         assert comm is None or dtype == torch.float32
         live = dist.is_available() and dist.is_initialized()
@@ -92,8 +93,10 @@ class GatherBuffer:
         if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             return (out, None) if async_op else out
         if self.comm is not None:
-            self.comm.all_gather_f32(self.send, self.full)
-            return (out, _Done()) if async_op else out
+            # stream-ordered on the CURRENT stream: a consumer on that stream needs nothing; with async_op the handle's wait() orders
+            # whatever stream is current THEN behind the collective (one event record; rccl.py, "Stream contract")
+            work = self.comm.all_gather_f32(self.send, self.full, want_handle=async_op)
+            return (out, work) if async_op else out
         if self.full.is_cuda and dist.get_backend(self.group) == "gloo":
             # ranks sharing a GPU (the two-ranks-on-one-GPU tests): gloo moves host memory, stage the few bytes through it
             host = self.send.cpu()

@@ -17,7 +17,8 @@
 // Modes: 0 shipped (8 v_sub |abs|, 8 v_alignbit, 4 v_min3 |abs|, v_cmp + ballot) . 5 MFMA alone . 8 VALU of mode 0 alone (no MFMA)
 //        6 knock-out: v_sub in its 32-bit VOP2 encoding on a pre-abs'd operand (no |abs| modifier, so no 64-bit VOP3 word)
 //        7 knock-out: two independent sign queues per tile (a 4-deep dependent v_alignbit chain instead of 8-deep)
-//        9 mode 0 without queue and band test (8 v_sub only)      3 / 4 as in count_pipe2 (no sign queue / no band test)
+//        9 mode 0 without queue and band test (8 v_sub only)      1 / 2 / 3 / 4 as in count_pipe2 (clamp counting with / without its
+//        detection; no sign queue; no band test)
 // The third knock-out (MFMA results in AGPRs) is the same source compiled WITHOUT -mllvm -amdgpu-mfma-vgpr-form.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form count_pipe3.hip -o build/mb/cp3
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize count_pipe3.hip -o build/mb/cp3_agpr
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) voi
         unsigned flagged = 0;
         unsigned qs[2] = {0u, 0u}, qb[2] = {0u, 0u};
         unsigned sink = 0u;
+        float cntf[2] = {0.f, 0.f}, sqf[2] = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (MODE == 8) asm volatile("" : "+v"(fake));       // (opaque: the VALU work is redone per tile, nothing is multiplied)
@@ -64,6 +66,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) voi
             if (MODE == 5) {
                 sink |= __float_as_uint(acc[0]);              // one v_or per MFMA keeps it alive; consumed in order (no 8-deep hoist)
                 asm volatile("" : "+v"(sink));
+                continue;
+            }
+            if (MODE == 1 || MODE == 2) {
+                // clamp counting (count_pipe2 modes 1 / 2): s = clamp(S t + 1/2) in {0, 1} outside the band (scale and 1/2 ride in the
+                // MFMA operands), count = sum s, band detection sum s^2 != sum s: 24 FULL-rate instructions instead of 8 + 13 half-rate
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sv = __builtin_amdgcn_fmed3f(acc[e] - fabsf(acc[8 + e]), 0.f, 1.f);   // folds into v_sub ... clamp
+                    cntf[e & 1] += sv;
+                    if (MODE == 1) sqf[e & 1] = __builtin_fmaf(sv, sv, sqf[e & 1]);
+                }
+                if (MODE == 1) { if (__ballot(cntf[0] + cntf[1] != sqf[0] + sqf[1]) != 0) flagged |= 1u << j; }
                 continue;
             }
             float tmin = INFINITY;
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) voi
             }
             if (MODE != 4 && MODE != 9) { if (__ballot(tmin <= Wb) != 0) flagged |= 1u << j; }
         }
-        total += 64 - __popc(qs[0]) - __popc(qs[1]) - __popc(qb[0]) - __popc(qb[1]) + (int)sink;
+        total += 64 - __popc(qs[0]) - __popc(qs[1]) - __popc(qb[0]) - __popc(qb[1]) + (int)sink + (int)(cntf[0] + cntf[1] + sqf[0] + sqf[1]);
         flagged_any |= flagged;
         asm volatile("" : "+v"(Bop));
     }
@@ -152,7 +166,13 @@ int main()
     run(tile_kernel<3, 5>, "3 without the sign queue (8 sub, 8 or, 4 min3, cmp)", 5, d, dst);
     run(tile_kernel<4, 5>, "4 without the band test (8 sub, 8 alignbit)", 5, d, dst);
     run(tile_kernel<9, 5>, "9 8 sub only (+8 shift-or to keep them alive)", 5, d, dst);
+    run(tile_kernel<1, 5>, "1 clamp counting (8 sub-clamp, 8 add, 8 fma, cmp: 2 chains)", 5, d, dst);
+    run(tile_kernel<2, 5>, "2 clamp counting without detection (8 sub-clamp, 8 add)", 5, d, dst);
     run(tile_kernel<0, 4>, "0 shipped at FOUR waves per SIMD", 4, d, dst);
+    run(tile_kernel<0, 6>, "0 shipped at SIX waves per SIMD", 6, d, dst);
+    run(tile_kernel<0, 8>, "0 shipped at EIGHT waves per SIMD", 8, d, dst);
+    run(tile_kernel<8, 8>, "8 VALU alone at EIGHT waves per SIMD", 8, d, dst);
+    run(tile_kernel<1, 8>, "1 clamp counting at EIGHT waves per SIMD", 8, d, dst);
     run(tile_kernel<0, 5>, "0 shipped, again", 5, d, dst);
     run(tile_kernel<5, 5>, "5 MFMA alone, again", 5, d, dst);
     return 0;
