@@ -9,8 +9,8 @@
 // The sqrt/divide-free VALU kernel of round 1 (k_count_fast, removed) was bound by VALU issue (7.35 VALU instructions per evaluation, 84 % VALU busy); 4 of the 6.5
 // useful ones are the two dot products a = d.nh and b' = kappa d x nh.  Those are bilinear in (hx,hy,1) and the
 // pixel's (nh, -c.nh) / (B, -c.B): a rank-3 form.  The f32 MFMA shares the fp32 VALU datapath on gfx950
-// (tools/microbench/mfma_valu_overlap.hip: no overlap), but the bf16 matrix core is a separate pipe that does
-// overlap (tools/microbench/bf16_mfma_overlap.hip).  So every fp32 operand is split EXACTLY into three bf16
+// (round 1's mfma_valu_overlap microbenchmark, profiles/r01_microbench.txt: no overlap), but the bf16 matrix core is a separate
+// pipe that does overlap (tools/microbench/bf16_mfma_overlap.hip; how much: tools/microbench/count_pipe3.hip, round 6).  So every fp32 operand is split EXACTLY into three bf16
 // pieces x = x0 + x1 + x2 (+ <= 2^-27 |x|), the six leading piece products of hx*nhx and of hy*nhy plus the three
 // pieces of the constant are the 15 terms of a K=16 dot product, and ONE v_mfma_f32_32x32x16_bf16 delivers a
 // (rows 0-15) and b' (rows 16-31) for 16 pixels x 32 hypotheses.  The VALU keeps t = a - |b'|, the sign-bit

@@ -98,7 +98,10 @@ bool fuse_sub_shape(const pvv_problem *p, int T)
 // when no mask of this shape can exceed max_num (the largest foreground_num: 255 per pixel, P:126).
 bool may_store_draws(const pvv_problem *p, int T)
 {
-    if ((long long)p->max_num >= 255ll * p->H * p->W) return false;
+    // (the largest per-pixel weight: a byte mask's 255, or the fused argmax's class index seg_classes - 1 -- make_front's max_weight;
+    // the workspace query cannot see which of the two the call will be, so the larger one decides: ADVICE r5)
+    const long long max_weight = std::max(255ll, (long long)p->seg_classes - 1);
+    if ((long long)p->max_num >= max_weight * p->H * p->W) return false;
     return !((p->flags & PVV_FLAG_DEVICE_RNG) && fuse_sub_shape(p, T));
 }
 
@@ -254,7 +257,7 @@ int stream_device(hipStream_t st)
         hipDevice_t d;
         if (hipStreamGetDevice(st, &d) == hipSuccess) dev = (int)d; else (void)hipGetLastError();
     }
-    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }     // (no sticky error on GPU-less hosts)
     return dev >= 0 && dev < 64 ? dev : -1;
 }
 
@@ -659,8 +662,12 @@ bool est_stage_auto(const pvv_problem *p, hipStream_t st)
 {
     if (p->hn < 1024) return false;
     double sum_tn = -1.0;
-    const float rho = stage_hint_mean(p, st, nullptr, &sum_tn, /*any_hn=*/true);
+    float max_tn = -1.f;
+    const float rho = stage_hint_mean(p, st, &max_tn, &sum_tn, /*any_hn=*/true);
     if (rho < 0.f || sum_tn < 0.0) return stage_proxy_work(p) >= kEstStageMinWork;
+    // (as in stage_hint_allows: when the last calls held no image of kStageMinChunks chunks, the first launch counts everything and
+    // k_lead + the second launch would only be launched to leave again)
+    if (!(max_tn > (float)((kStageMinChunks - 1) * 4 * kBfPixPerWave))) return false;
     const double work = (double)p->K * p->hn * sum_tn / kStageProxyFg;
     return work >= (rho >= 0.95f ? 6e10 : (rho >= 0.85f ? 9e10 : kEstStageMinWork));
 }
@@ -1202,8 +1209,13 @@ PVV_EXPORT int pvv_decode_keypoint_un_pnp(const pvv_problem *p, int32_t hn_est, 
         const size_t set_bytes = sizeof(int) * lead_set_words(p);
         // the second pass's leader words (k_compact_hyp zeroes the first set): cleared up front, off the kernels' chain
         if (hipMemsetAsync(ws + L.lead + set_bytes, 0, set_bytes, st) != hipSuccess) return fail(PVV_E_ARG, "hipMemsetAsync(leader words) failed");
+        // the caller's event pair spans BOTH count passes (and the refit between them): begin is recorded by the first pass only,
+        // end by the second only -- a consumer never sees the estimate's pass alone
+        pvv_problem p1 = *p;
+        p1.ev_count_end = nullptr;
+        pe.ev_count_begin = nullptr;
         CountPlan plan;
-        plan.p = p;
+        plan.p = &p1;
         plan.staged = decide_staged(p, L, st, 1);
         plan.cols.col0 = 0; plan.cols.hstride = q.hn; plan.cols.lead_set = 0;
         if (int e = run_front(&q, 0, nullptr, d_vertex, d_idxs, d_selection, ws, L, st, d_tn, d_seg, d_mask_out, d_idxs_est,

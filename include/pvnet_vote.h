@@ -127,8 +127,10 @@ typedef struct pvv_problem {
                                 p->hn + hn_est */
     void *ev_count_begin;    /* optional hipEvent_t pair (NULL = off), recorded on `stream` immediately before and   */
     void *ev_count_end;      /* after the inlier-count launch of THIS call: the dominant kernel's duration as it runs
-                                inside the pipeline (a measurement aid: tools/count_kernel_timing.py compares it with
-                                re-launches of the kernel alone, a differential measurement and rocprofv3) */
+                                inside the pipeline (a measurement aid).  pvv_decode_keypoint_un_pnp counting its rows as
+                                two passes records begin before the first and end after the second: the pair then spans
+                                v3's count pass, the refit and the estimate's count pass; its PVV_MARK_END (ev_marks) is
+                                recorded behind the refit, i.e. BEFORE the estimate's pass */
     /* ---- ABI v6 ---- */
     int32_t *d_status;       /* optional DEVICE buffer [B] i32 (NULL = off): PVV_STATUS_* bits per image, written with tn.
                                 The one condition a caller cannot see otherwise is PVV_STATUS_TRUNCATED: the subsample of
@@ -189,15 +191,18 @@ typedef struct pvv_problem {
  * tie rule, winner count and refit are bit-identical to the full pass; what differs is that the counters of eliminated
  * hypotheses hold partial counts (they are not an output of v3).  AUTO stages when the batch is large enough for the
  * two extra launches to pay; FULL = the matrix-core kernel over everything, never staged; STAGED = staged wherever the
- * matrix-core kernel is valid (what the tests force at every size).  The fused un_pnp pass weighs every hypothesis and
- * always counts in full; the estimate weighs those within 0.1 of the best ratio and, since ABI v8, counts in stages against that
- * bound where it pays (AUTO on large batches: pvv_estimate_counts_in_stages; never when its counts are an output). */
+ * matrix-core kernel is valid (what the tests force at every size).  The estimate weighs the hypotheses within 0.1 of the best
+ * ratio and, since ABI v8, counts in stages against that bound where it pays (AUTO: est_stage_auto -- the stage hint of the v3
+ * call that precedes every estimate, from ~6 LINEMOD frames on; pvv_estimate_counts_in_stages tells; never when its counts are
+ * an output).  The fused un_pnp call (pvv_decode_keypoint_un_pnp) follows the same rule: where the estimate alone would stage,
+ * its rows are counted as TWO passes -- v3's columns, then the estimate's against its bound -- otherwise as one full pass. */
 #define PVV_COUNT_FULL 2
 #define PVV_COUNT_STAGED 3
 /* ABI v8: PVV_COUNT_STAGED stages ransac_voting_layer_v3 only (its v6 meaning; under v7 it also staged an estimate whose
  * counts are not an output).  The estimate counted in stages against its own bound (every hypothesis whose ratio can still
- * come within 0.1 of the best, P:262-264) is exact but not faster than the full pass at most sizes, so it
- * has its own value: what the tests use to cross-check that bound.  For v3 calls it behaves like PVV_COUNT_STAGED. */
+ * come within 0.1 of the best, P:262-264) is exact and, since round 5, faster than the full pass from ~6 LINEMOD frames on
+ * (staged / full 0.83-0.85 at B = 24-64, >= 1.0 below 6 frames: DESIGN.md 4.2), which is where AUTO takes it; this value FORCES it
+ * at every size: what the tests use to cross-check the bound.  For v3 calls it behaves like PVV_COUNT_STAGED. */
 #define PVV_COUNT_STAGED_ESTIMATE 4
 
 /* b_inv (P:97-109) falls back to the identity for the WHOLE image when the

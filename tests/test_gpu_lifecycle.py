@@ -107,3 +107,14 @@ def test_rerun_count_kernel_on_a_lean_workspace(synth, pkg, gpu):
     out2, win2, _t, _w = ext.ransac_voting_v3(d["mask"], d["vertex"], 512, 0.99, 5, 30000, None, None, 3, ext.SINGULAR_REFERENCE,
                                               count_kernel=ext.COUNT_FULL)
     assert torch.equal(out, out2) and torch.equal(win, win2)
+    # a workspace made by a call that INJECTED its index pairs reserves draw storage; re-running it under the default
+    # device_rng=True would shift every offset behind the tile lists -- that must be an error, not a count on garbage
+    tn = [int(x) for x in (d["mask"] != 0).sum((1, 2))]
+    idxs = synth.make_idxs(tn, 512, 9).to(gpu)
+    out3, win3, _t3, ws3 = ext.ransac_voting_v3(d["mask"], d["vertex"], 512, 0.99, 5, 30000, idxs, None, 3, ext.SINGULAR_REFERENCE,
+                                                count_kernel=ext.COUNT_FULL)
+    assert ws3.numel() > ws.numel()
+    with pytest.raises(RuntimeError, match="device_rng"):
+        ext.rerun_count_kernel(d["mask"], d["vertex"], 512, 0.99, 5, 30000, ws3, True, ext.COUNT_FULL)
+    ext.rerun_count_kernel(d["mask"], d["vertex"], 512, 0.99, 5, 30000, ws3, True, ext.COUNT_FULL, device_rng=False)
+    torch.cuda.synchronize()

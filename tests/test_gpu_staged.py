@@ -390,8 +390,8 @@ def test_run_owning_filter_launch_branches(synth, pkg, gpu, B, H, W, K, hn, fg, 
 def test_estimate_counted_in_stages_equals_the_full_pass(synth, pkg, gpu, B, H, W, K, hn, fg, outlier):
     """estimate_voting_distribution_with_mean zeroes every ratio below (max ratio - 0.1) in binary32 (P:262-264, k_covariance), so a
     count pass in stages may drop what provably falls below that window (stage_bound: L* - ceil(tn / 10) - margin).  Forced with
-    PVV_COUNT_STAGED_ESTIMATE (ABI v8; AUTO never takes it -- exact but not faster, DESIGN.md 4 -- and PVV_COUNT_STAGED stages v3
-    only): covariances and PnP weights equal the full pass bit for bit; a call that asks for the counts themselves is always
+    PVV_COUNT_STAGED_ESTIMATE (ABI v8; AUTO takes it from ~6 LINEMOD frames on -- est_stage_auto and the stage hint, DESIGN.md 4.2 --
+    and PVV_COUNT_STAGED stages v3 only): covariances and PnP weights equal the full pass bit for bit; a call that asks for the counts themselves is always
     counted in full."""
     from clean_pvnet_amd import ransac_voting as ext
     d = synth.make_batch(B=B, H=H, W=W, K=K, fg=fg, sigma=0.05, outlier=outlier, seed=5100 + B, device=gpu)
