@@ -1,5 +1,10 @@
 // Round 5: what the VALU side of the count kernel's per-tile loop costs, form by form, at the kernel's own occupancy
 // (5 waves per SIMD, 96-register budget), beside the bf16 matrix-core instruction it consumes.  Relative numbers in one run:
+// NOTE (round 6) on this file's UNITS: its "cycles per tile and SIMD" are ONE WAVE's s_memtime cycles per tile divided by 5 -- the SIMD's
+// figure only if all five waves ran their loops over the whole kernel (they do not: waves of one SIMD finish up to a millisecond apart) -- and
+// its "clock" is wave cycles / kernel time, low for the same reason (1.45-1.67 "GHz" where the chip ran at 2.3; also why "MFMA alone" read
+// 23.3 where the matrix pipe needs 32-34 cycles).  count_pipe3.hip reads both device counters (s_memtime, s_memrealtime) and the kernel time and
+// prints per-wave and per-SIMD figures separately: use that.  Kept because profiles/r05_count_pipe2.txt quotes this one.
 //   0  as shipped: 8 v_sub |abs|, 8 v_alignbit (sign queue), 4 v_min3 |abs| (band test), v_cmp + ballot
 //   1  clamp counting: 8 v_sub |abs| clamp (s = clamp(S t + 1/2): the scale S and the 1/2 ride in the MFMA operands), 8 v_add
 //      (count), 8 v_fma (sum of squares: equal to the count iff no s is fractional, i.e. no evaluation in the band), v_cmp + ballot
