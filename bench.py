@@ -1067,7 +1067,7 @@ def cpu_leg(mask, vertex, tn, hn, K, thresh, n_sample, synth, ext, rep_s=1.0, re
         return vote_oracle.ransac_voting_layer_v3(m[i:i + 1], v[i:i + 1], hn, thresh, idxs=idxs[i:i + 1], details=det, compact_in_c=True)
 
     def rate(nthr):
-        """-> images/s of `reps` repetitions of >= rep_s seconds at nthr OpenMP threads"""
+        """-> images/s of `reps` repetitions of >= rep_s seconds at nthr OpenMP threads, HYPOTHESIS-parallel (one image at a time)"""
         vote_oracle.set_num_threads(nthr)
         one(0)
         out = []
@@ -1078,16 +1078,42 @@ def cpu_leg(mask, vertex, tn, hn, K, thresh, n_sample, synth, ext, rep_s=1.0, re
                 done += 1
             out.append(done / (time.perf_counter() - t0))
         return sorted(out)
+
+    def rate_images(nthr):
+        """-> images/s at nthr OpenMP threads, IMAGE-parallel (orc_v3_batch: one thread per image, serial inside; round 6, VERDICT
+        r5 #5): `reps` repetitions, each one C call over enough images for >= rep_s seconds (sized from a first call of one image per
+        thread)"""
+        vote_oracle.set_num_threads(nthr)
+        t0 = time.perf_counter()
+        vote_oracle.v3_batch(m, v, hn, thresh, idxs, total=nthr)
+        per_round = max(1e-3, time.perf_counter() - t0)                  # seconds for one image per thread
+        total = max(nthr, int(nthr * min(64.0, max(1.0, rep_s / per_round))))
+        out = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            vote_oracle.v3_batch(m, v, hn, thresh, idxs, total=total)
+            out.append(total / (time.perf_counter() - t0))
+        return sorted(out)
     single = rate(1)
-    # host CPUs visible != CPUs usable (cgroup quotas): the thread count is chosen by measurement
+    # host CPUs visible != CPUs usable (cgroup quotas): the thread count is chosen by measurement, and the quota is printed
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            quota = {"file": path, "content": open(path).read().strip()}
+            break
+        except OSError:
+            pass
     cand = sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 8)}, reverse=True)
     table, best = [], None
-    for nthr in cand:
-        r = rate(nthr)
-        table.append({"threads": nthr, "images_per_s_median": round(r[len(r) // 2], 2), "min": round(r[0], 2), "max": round(r[-1], 2)})
-        if best is None or r[len(r) // 2] > best[1][len(best[1]) // 2]:
-            best = (nthr, r)
+    for form, fn in (("hypothesis_parallel", rate), ("image_parallel", rate_images)):
+        for nthr in cand:
+            if form == "image_parallel" and nthr * (2 * 4 * (1 + K) * int(m.shape[1]) * int(m.shape[2])) > 48 * 2 ** 30:
+                continue                                                 # (per-thread scratch: coords + direct of a whole image)
+            r = fn(nthr)
+            table.append({"form": form, "threads": nthr, "images_per_s_median": round(r[len(r) // 2], 2), "min": round(r[0], 2), "max": round(r[-1], 2)})
+            if best is None or r[len(r) // 2] > best[1][len(best[1]) // 2]:
+                best = (nthr, r, form)
     vote_oracle.set_num_threads(best[0])
     outs, wins = {}, {}
     for i in range(n):                                               # the cross-check: every sampled image once, untimed
@@ -1108,12 +1134,14 @@ def cpu_leg(mask, vertex, tn, hn, K, thresh, n_sample, synth, ext, rep_s=1.0, re
     r = best[1]
     return {"value": round(r[len(r) // 2], 3), "unit": "images/s", "cores": best[0], "kind": "port",
             "spread": {"min": round(r[0], 3), "max": round(r[-1], 3), "repetitions": reps, "seconds_each": rep_s},
-            "sample": "single-image ransac_voting_layer_v3 calls of the oracle cycling over %d of the timed 480x640 images, everything in "
-                      "C (orc_compact_v3 + orc_v3_image: OpenMP over hypotheses); %d repetitions of >= %.1f s per thread count, the "
-                      "median of the best count" % (n, reps, rep_s),
+            "form": best[2],
+            "sample": "ransac_voting_layer_v3 of the oracle cycling over %d of the timed 480x640 images, everything in C (orc_compact_v3 + "
+                      "orc_v3_image), timed two ways -- hypothesis-parallel (OpenMP inside one image, image after image) and image-parallel "
+                      "(orc_v3_batch: one thread per image, serial inside) -- at %d thread counts each, %d repetitions of >= %.1f s; `value` = "
+                      "the best median, `cores` = its thread count, `form` = which of the two" % (n, len(cand), reps, rep_s),
             "single_thread": {"value": round(single[len(single) // 2], 3), "unit": "images/s", "cores": 1,
                               "spread": {"min": round(single[0], 3), "max": round(single[-1], 3)}},
-            "cpu_model": model, "host_cpus": os.cpu_count(), "usable_cpus": avail,
+            "cpu_model": model, "host_cpus": os.cpu_count(), "usable_cpus": avail, "sched_getaffinity_count": avail, "cgroup_cpu_quota": quota,
             "thread_probe": {"table": table, "picked": best[0],
                              "how": "%d repetitions of >= %.1f s per candidate thread count, the same loop as the figure itself (visible CPUs != "
                                     "usable CPUs under cgroup quotas: the figure varies from box to box -- quote it with this table)" % (reps, rep_s)},

@@ -325,6 +325,67 @@ ORC_API long long orc_compact_v3(const void *mask, int es, const float *vertex, 
     return fg;
 }
 
+/* ransac_voting_gpu.py:123-199 for `total` images, IMAGE-PARALLEL: one OpenMP thread per image, everything inside an image
+ * serial (orc_compact_v3 + orc_v3_image; their inner `omp parallel for` regions run on the one thread: nested parallelism is off).
+ * Images are independent units (the reference's `for bi in range(b)`, :123), so this is how a host would use all of its cores;
+ * bench.py's cpu_baseline leg times it beside the hypothesis-parallel single-image form and reports the better (round 6, VERDICT
+ * r5 #5: the hypothesis-parallel form stops scaling at 8 threads).  Image j of the run is sample j % n of masks [n,H,W] (es-byte
+ * integers) / vertex [n,H,W,vn,2] / idxs [n,hn,vn,2].  b_inv's policy is the reference's (:97-109: one singular keypoint -> x = ATb for
+ * the whole image).  out [n,vn,2] / win_counts [n,vn] receive the results of the FIRST pass over each sample (j < n; zeros / -1 for
+ * an image below min_num): later passes recompute and discard, so no two threads ever write one row.  No subsampling support (max_num must not be exceeded: returns -2); -1 on allocation failure; else `total`. */
+ORC_API int orc_v3_batch(const void *masks, int es, const float *vertex, const int32_t *idxs, int n, int H, int W, int vn, int hn,
+                         float thresh, int min_num, int max_num, int total, float *out, int32_t *win_counts)
+{
+    const size_t HW = (size_t)H * W;
+    int status = total;
+#pragma omp parallel
+    {
+        float *coords = (float *)malloc(sizeof(float) * 2 * HW);
+        float *direct = (float *)malloc(sizeof(float) * 2 * HW * (size_t)vn);
+        float *hypo = (float *)malloc(sizeof(float) * 2 * (size_t)hn * vn);
+        int32_t *counts = (int32_t *)malloc(sizeof(int32_t) * (size_t)hn * vn);
+        float *win_pts = (float *)malloc(sizeof(float) * 2 * vn), *pts = (float *)malloc(sizeof(float) * 2 * vn);
+        int32_t *wc = (int32_t *)malloc(sizeof(int32_t) * 3 * vn);
+        double *AT = (double *)malloc(sizeof(double) * 5 * vn);
+        const int ok = coords && direct && hypo && counts && win_pts && pts && wc && AT;
+        if (!ok) {
+#pragma omp critical
+            status = -1;
+        }
+#pragma omp for schedule(dynamic, 1)
+        for (int j = 0; j < total; ++j) {
+            if (!ok) continue;
+            const int i = j % n;
+            int tn = 0;
+            const long long fg = orc_compact_v3((const uint8_t *)masks + (size_t)i * HW * es, es, vertex + (size_t)i * HW * vn * 2, H, W, vn,
+                                                NULL, max_num, coords, direct, (int)HW, &tn);
+            float *o = out + (size_t)i * vn * 2;
+            const int keep = j < n;
+            if (tn < 0) {
+#pragma omp critical
+                status = -2;
+                continue;
+            }
+            if (fg < (long long)min_num) {                       /* :129-132 */
+                if (keep)
+                    for (int k = 0; k < vn; ++k) { o[2 * k] = 0.f; o[2 * k + 1] = 0.f; win_counts[(size_t)i * vn + k] = -1; }
+                continue;
+            }
+            orc_v3_image(direct, coords, idxs + (size_t)i * hn * vn * 2, tn, vn, hn, thresh, hypo, counts, win_pts, wc, wc + vn,
+                         AT, AT + 3 * vn, wc + 2 * vn, pts);
+            int any_sing = 0;
+            for (int k = 0; k < vn; ++k) any_sing |= wc[2 * vn + k];
+            for (int k = 0; keep && k < vn; ++k) {
+                o[2 * k] = any_sing ? (float)AT[3 * vn + 2 * k] : pts[2 * k];
+                o[2 * k + 1] = any_sing ? (float)AT[3 * vn + 2 * k + 1] : pts[2 * k + 1];
+                win_counts[(size_t)i * vn + k] = wc[k];
+            }
+        }
+        free(coords); free(direct); free(hypo); free(counts); free(win_pts); free(pts); free(wc); free(AT);
+    }
+    return status;
+}
+
 /* ransac_voting_gpu.py:231-269 for ONE compacted image.               */
 /* idxs [hn_total,vn,2] holds the `round_num` rounds concatenated      */
 /* (:235,249), `foreground` is tn as float (:244).                     */

@@ -293,6 +293,29 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     return out
 
 
+def v3_batch(mask, vertex, round_hyp_num, inlier_thresh, idxs, min_num=5, max_num=30000, total=None):
+    """``ransac_voting_layer_v3`` (singular="reference") over ``total`` images cycling through the ``n`` samples given, IMAGE-PARALLEL in C
+    (``orc_v3_batch``: one OpenMP thread per image, serial inside -- the form that uses a host's cores; what bench.py's cpu_baseline leg
+    times beside the hypothesis-parallel single-image form).  -> (out [n,vn,2], win_counts [n,vn], -1 rows for skipped images)."""
+    m = np.ascontiguousarray(mask)
+    if m.dtype == np.bool_:
+        m = m.view(np.uint8)
+    assert m.dtype.kind in "iu" and m.ndim == 3, (m.dtype, m.shape)
+    v = _c(vertex, np.float32)
+    n, H, W, vn, _ = v.shape
+    ix = _c(idxs, np.int32)
+    assert ix.shape == (n, round_hyp_num, vn, 2) and m.shape == (n, H, W)
+    out = np.zeros((n, vn, 2), np.float32)
+    win = np.zeros((n, vn), np.int32)
+    f = lib().orc_v3_batch
+    f.restype = ctypes.c_int
+    rc = f(m.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(m.dtype.itemsize), _p(v, _f32p), _p(ix, _i32p), n, H, W, vn,
+           int(round_hyp_num), ctypes.c_float(inlier_thresh), int(min_num), int(max_num), int(n if total is None else total),
+           _p(out, _f32p), _p(win, _i32p))
+    assert rc >= 0, "orc_v3_batch failed: %d (-1 allocation, -2 an image exceeds max_num: subsampling is not supported here)" % rc
+    return out, win
+
+
 def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256, min_hyp_num=4096,
                                            topk=128, inlier_thresh=0.99, min_num=5, max_num=30000,
                                            output_hyp=False, *, idxs, selection=None, details=None):

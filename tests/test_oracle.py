@@ -269,3 +269,34 @@ def test_c_compaction_equals_the_numpy_restatement(oracle):
     o1 = oracle.ransac_voting_layer_v3(m, v[None], 32, 0.99, idxs=idxs)
     o2 = oracle.ransac_voting_layer_v3(m, v[None], 32, 0.99, idxs=idxs, compact_in_c=True)
     assert np.array_equal(o1, o2)
+
+
+def test_image_parallel_batch_equals_the_single_image_calls(oracle, synth):
+    """orc_v3_batch (round 6: the image-parallel loop bench.py's cpu_baseline leg times -- one OpenMP thread per image, serial
+    inside) against ransac_voting_layer_v3 image by image: keypoints and winner counts equal bit for bit, for int64 and uint8 masks,
+    an empty image, an image with a singular keypoint (b_inv's whole-image x = ATb, ransac_voting_gpu.py:97-109) and more passes
+    than samples (total > n: results are those of the first pass)."""
+    cfg = {**synth.CONFIGS["cfg1"], "B": 5}
+    d = synth.make_batch(**cfg)
+    mask, vertex = d["mask"].numpy().copy(), d["vertex"].numpy().copy()
+    mask[3] = 0                                                      # below min_num: zeros
+    K, hn = cfg["K"], cfg["hn"]
+    vertex[4, ..., 1, :] = 0.0                                       # keypoint 1 of image 4: no pixel can vote -> count 0 -> singular
+    tn = [int(x) for x in (mask != 0).sum((1, 2))]
+    idxs = synth.make_idxs([max(t, 1) for t in tn], hn, K).numpy()
+    det = []
+    want = oracle.ransac_voting_layer_v3(mask, vertex, hn, 0.99, idxs=idxs, details=det)
+    assert det[3].get("skipped") and det[4]["singular"].any()
+    before = oracle.num_threads()
+    for m in (mask, mask.astype(np.uint8)):
+        for total in (None, 13):
+            for nthr in (1, 3):
+                oracle.set_num_threads(nthr)
+                got, win = oracle.v3_batch(m, vertex, hn, 0.99, idxs, total=total)
+                np.testing.assert_array_equal(got, want)
+                for i in range(5):
+                    if det[i].get("skipped"):
+                        assert (win[i] == -1).all()
+                    else:
+                        np.testing.assert_array_equal(win[i], det[i]["win_counts"])
+    oracle.set_num_threads(before)
