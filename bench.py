@@ -1104,7 +1104,16 @@ def cpu_leg(mask, vertex, tn, hn, K, thresh, n_sample, synth, ext, rep_s=1.0, re
             break
         except OSError:
             pass
-    cand = sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 8)}, reverse=True)
+    cand = {avail, max(1, avail // 2), max(1, avail // 4), min(avail, 8)}
+    quota_cpus = None
+    try:                                                                 # cgroup v2 "quota period": the CPUs' worth of time this job may use
+        q, per = quota["content"].split()[:2]
+        if q != "max":
+            quota_cpus = max(1, -(-int(q) // int(per)))
+            cand |= {min(avail, quota_cpus), min(avail, 2 * quota_cpus)}
+    except Exception:                                                    # noqa: BLE001  (no quota file, or cgroup v1's single number)
+        pass
+    cand = sorted(cand, reverse=True)
     table, best = [], None
     for form, fn in (("hypothesis_parallel", rate), ("image_parallel", rate_images)):
         for nthr in cand:
@@ -1141,7 +1150,7 @@ def cpu_leg(mask, vertex, tn, hn, K, thresh, n_sample, synth, ext, rep_s=1.0, re
                       "the best median, `cores` = its thread count, `form` = which of the two" % (n, len(cand), reps, rep_s),
             "single_thread": {"value": round(single[len(single) // 2], 3), "unit": "images/s", "cores": 1,
                               "spread": {"min": round(single[0], 3), "max": round(single[-1], 3)}},
-            "cpu_model": model, "host_cpus": os.cpu_count(), "usable_cpus": avail, "sched_getaffinity_count": avail, "cgroup_cpu_quota": quota,
+            "cpu_model": model, "host_cpus": os.cpu_count(), "usable_cpus": avail, "sched_getaffinity_count": avail, "cgroup_cpu_quota": quota, "cgroup_quota_cpus": quota_cpus,
             "thread_probe": {"table": table, "picked": best[0],
                              "how": "%d repetitions of >= %.1f s per candidate thread count, the same loop as the figure itself (visible CPUs != "
                                     "usable CPUs under cgroup quotas: the figure varies from box to box -- quote it with this table)" % (reps, rep_s)},

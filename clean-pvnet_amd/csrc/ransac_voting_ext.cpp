@@ -577,10 +577,15 @@ void rerun_count_kernel(at::Tensor mask, at::Tensor vertex, int64_t hn, double i
     }
     check_dev(ws, "workspace", at::kByte);
     // ransac_voting_v3 sizes its workspace to exactly pvv_workspace_bytes of ITS problem: a different total here means different
-    // flags / cap / hn, i.e. every offset behind the tile lists would be shifted and the kernel would count on garbage
-    TORCH_CHECK((size_t)ws.numel() == pvv_workspace_bytes(&p),
+    // flags / cap / hn, i.e. every offset behind the tile lists would be shifted and the kernel would count on garbage.
+    // (The staged pass's leader words and miss counters come LAST in the layout, so a workspace made under AUTO / STAGED serves a
+    // re-run of the full pass: the two totals that differ only in that tail are both accepted.)
+    pvv_problem p_auto = p;
+    p_auto.count_kernel = PVV_COUNT_AUTO;
+    TORCH_CHECK((size_t)ws.numel() == pvv_workspace_bytes(&p) || (size_t)ws.numel() == pvv_workspace_bytes(&p_auto),
                 "rerun_count_kernel: the workspace holds ", ws.numel(), " bytes but this problem lays out ", pvv_workspace_bytes(&p),
-                ": pass device_rng=False if the producing call injected idxs or selection, and the same hn / cap");
+                " (", pvv_workspace_bytes(&p_auto), " with the staged pass's tail): pass device_rng=False if the producing call injected idxs "
+                "or selection, and the same hn / cap");
     ok(pvv_rerun_count_kernel(&p, ws.data_ptr(), (size_t)ws.numel(), zero_counts ? 1 : 0, cur_stream(vertex)),
        "rerun_count_kernel");
 }
