@@ -135,40 +135,70 @@ def test_reference_estimate_on_hip_kernels_equals_golden_and_the_fused_layer(ora
     tol.assert_cov_close(cov_ref, c["cov"], rtol=2 * tol.COV_RTOL_VS_REFERENCE_F32, what="reference glue on HIP vs golden")
 
 
-def test_reference_glue_at_linemod_size_vs_the_fused_layer(oracle, synth, pkg, gpu, ref):
-    """BASELINE config 2 (480x640, K = 9, 512 hypotheses, one image): the reference's glue draws from torch's device
-    generator, the draws are recorded and injected into the product -- how far is the binary64 refit from what the
-    reference's float32 glue returns at the size the metric is quoted on?  (Weak #1 of VERDICT r3: a number.)"""
+# (config, image seed, what it stresses)
+GLUE_CASES = [("cfg2", 4242, "LINEMOD size: tn ~ 6100"),
+              ("cfg4", 4243, "Occlusion-LINEMOD: sparse occluded mask, 30-50 % outlier pixels, 1024 hypotheses"),
+              ("cfg5", 4244, "T-LESS size: 540x720, K = 17, 2048 hypotheses, foreground above max_num -> the subsample of P:135-138 with injected draws, tn ~ 30000")]
+
+
+@pytest.mark.parametrize("cfgname,seed,what", GLUE_CASES)
+def test_reference_glue_per_config_vs_the_fused_layer(oracle, synth, pkg, gpu, ref, cfgname, seed, what):
+    """One image of BASELINE configs 2 / 4 / 5 through THE REFERENCE'S OWN float32 glue (on the HIP kernels) and through the
+    product on the same draws: the reference's glue draws its index pairs from torch's device generator (recorded, injected into
+    the product), config 5's subsample draws are injected into both.  Counts and winners are identical; how far is the binary64
+    refit from what the reference's float32 glue returns, and how far is each from the EXACT least-squares solution of the same
+    inlier sets (rational arithmetic)?  The three numbers per config are printed, written to $PVV_EVIDENCE_DIR (tracked as
+    profiles/r06_ref_glue_deviation.json) and quoted in INTEGRATION.md (a maintainer comparing against
+    a CUDA run must find the deviation documented for the size they run)."""
+    import json
     import clean_pvnet_amd.ransac_voting_gpu as product
     import lib.csrc.ransac_voting.ransac_voting as ext
-    cfg = {**synth.CONFIGS["cfg2"], "B": 1}
+    cfg = {**synth.CONFIGS[cfgname], "B": 1}
     hn = cfg.pop("hn")
-    dd = synth.make_batch(**cfg, seed=4242)
+    dd = synth.make_batch(**cfg, seed=seed)
     mask, vertex = dd["mask"].to(gpu), dd["vertex"].to(gpu)
+    fg = int((dd["mask"] != 0).sum())
+    sel = None
+    if fg > 30000:                                                                    # P:134-138 will subsample: the same U(0,1) field for both
+        sel = torch.rand(1, cfg["H"], cfg["W"], generator=torch.Generator().manual_seed(seed + 1))
     torch.manual_seed(7)
-    d = refglue.Draws(ext)
+    d = refglue.Draws(ext, selection=None if sel is None else [sel[0]])
     ref.ransac_voting = d
     try:
-        out_ref = ref.ransac_voting_layer_v3(mask, vertex, hn, inlier_thresh=0.99)
+        with d.patch_uniform():
+            out_ref = ref.ransac_voting_layer_v3(mask, vertex, hn, inlier_thresh=0.99)
     finally:
         ref.ransac_voting = ext
-    assert len(d.drawn) == 1
+    assert len(d.drawn) == 1 and not d.selection
     idxs = d.drawn[0][None]
-    ours = product.ransac_voting_layer_v3(mask, vertex, hn, inlier_thresh=0.99, idxs=idxs)
+    sel_g = None if sel is None else sel.to(gpu)
+    ours = product.ransac_voting_layer_v3(mask, vertex, hn, inlier_thresh=0.99, idxs=idxs, selection=sel_g)
     # the winners the two paths refit are the same hypotheses with the same counts
-    o2, win, tn, _ws = ext.ransac_voting_v3(mask, vertex, hn, 0.99, 5, 30000, idxs, None, 0, ext.SINGULAR_REFERENCE)
+    o2, win, tn, _ws = ext.ransac_voting_v3(mask, vertex, hn, 0.99, 5, 30000, idxs, sel_g, 0, ext.SINGULAR_REFERENCE)
     votes = [c for c in d.calls if c[0] == "voting_for_hypothesis"]
+    assert votes[0][1].shape[0] == int(tn[0])                                         # the same foreground pixels survived
     counts_ref = votes[0][4].sum(2, dtype=torch.int32)                               # [hn,vn]: P:159
     assert torch.equal(counts_ref.max(0).values, win[0])
     assert torch.equal(votes[-1][4].sum(2, dtype=torch.int32)[0], win[0])            # the re-vote of P:183 counts the same inliers
-    exact = tol.exact_v3(oracle, _np(mask), _np(vertex), hn, 0.99, _np(idxs))
+    exact = tol.exact_v3(oracle, _np(mask), _np(vertex), hn, 0.99, _np(idxs), selection=None if sel is None else sel.numpy())
     out_ref, ours = _np(out_ref), _np(ours)
-    print("\n[ref-glue] cfg2 480x640 K=9 hn=512 tn=%d: max|ours-ref_on_hip| = %.3g px; vs the exact solution: ours %.3g, "
-          "reference float32 glue %.3g px" % (int(tn[0]), np.abs(ours - out_ref).max(), np.abs(ours - exact).max(),
-                                              np.abs(out_ref - exact).max()))
+    row = {"config": cfgname, "what": what, "H": cfg["H"], "W": cfg["W"], "K": cfg["K"], "hn": hn, "tn": int(tn[0]),
+           "winner_ratio_min": round(float(win[0].min()) / max(1, int(tn[0])), 4),
+           "max_abs_ours_minus_reference_glue_px": float("%.3g" % np.abs(ours - out_ref).max()),
+           "max_abs_ours_minus_exact_px": float("%.3g" % np.abs(ours - exact).max()),
+           "max_abs_reference_glue_minus_exact_px": float("%.3g" % np.abs(out_ref - exact).max()),
+           "counts_and_winners_identical": True}
+    print("\n[ref-glue] %s %dx%d K=%d hn=%d tn=%d: max|ours-ref_on_hip| = %.3g px; vs the exact solution: ours %.3g, "
+          "reference float32 glue %.3g px" % (cfgname, cfg["H"], cfg["W"], cfg["K"], hn, int(tn[0]), row["max_abs_ours_minus_reference_glue_px"],
+                                              row["max_abs_ours_minus_exact_px"], row["max_abs_reference_glue_minus_exact_px"]))
+    out_dir = os.environ.get("PVV_EVIDENCE_DIR")
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "ref_glue_deviation.jsonl"), "a") as f:
+            f.write(json.dumps(row) + "\n")
     tol.assert_means_close(ours, exact)
     tol.assert_means_close(ours, out_ref, extra=np.abs(out_ref - exact), what="ours vs the reference's glue on the HIP kernels")
-    assert np.abs(out_ref - exact).max() < 5e-3                                      # float32 sums of ~1e7-sized terms
+    assert np.abs(out_ref - exact).max() < 5e-2                                      # float32 sums of ~1e7..1e8-sized terms
 
 
 @pytest.mark.parametrize("un_pnp", [False, True])
