@@ -29,4 +29,8 @@ python -c "import json,sys; json.dump([json.loads(l) for l in open(sys.argv[1]) 
 python tools/auto_regret.py --out $OUT/auto_regret.json > $OUT/auto_regret.log 2>&1
 if [ -f build/variants/stamps.so ]; then PVV_LIBPATH=build/variants/stamps.so python tools/census_filter.py --cases cfg3:64,cfg5:16 --out $OUT/filter_census.json > $OUT/census.log 2>&1; fi
 if [ -x build/mb/cp2 ]; then build/mb/cp2 > $OUT/count_pipe2.txt 2>&1; fi
+# round 6: the effective shader clock INSIDE the count kernels + the phase census of k_count_bf16 (same instrumented build), and the
+# per-tile loop microbenchmark with both device counters (hipcc ... tools/microbench/count_pipe3.hip -o build/mb/cp3, built before the call)
+if [ -f build/variants/stamps.so ]; then PVV_LIBPATH=build/variants/stamps.so python tools/census_count.py --out $OUT/count_census.json > $OUT/count_census.log 2>&1; fi
+if [ -x build/mb/cp3 ]; then build/mb/cp3 > $OUT/count_pipe3.txt 2>&1; fi
 tail -3 $OUT/profile.log; tail -c 600 $OUT/bench_default.json; grep -c "" $OUT/configs.log

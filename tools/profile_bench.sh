@@ -22,7 +22,7 @@ rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_
 # the side paths: v3 + estimate (un_pnp) and the fused decode on the real caller's layout, 12 calls each
 mkdir -p $OUT/side
 rocprofv3 --kernel-trace --stats -d $OUT/side/trace -o trace --output-format csv -- $SIDE > $OUT/side_trace.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES -d $OUT/side/pmc1 -o pmc1 --output-format csv -- $SIDE > $OUT/side_pmc1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU -d $OUT/side/pmc1 -o pmc1 --output-format csv -- $SIDE > $OUT/side_pmc1.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE -d $OUT/side/pmc2 -o pmc2 --output-format csv -- $SIDE > $OUT/side_pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/side/pmc3 -o pmc3 --output-format csv -- $SIDE > $OUT/side_pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/side/pmc4 -o pmc4 --output-format csv -- $SIDE > $OUT/side_pmc4.log 2>&1

@@ -97,6 +97,34 @@ WIDE_STREAMS = {"k_tile_scan": "8 B per lane, unit stride, read once: calibrated
                 "k_tile_scan_seg2": "16 B per lane streaming read of two f32 planes: x2 (MI355X_MICROARCH.md, HBM); known byte count B*2*H*W*4"}
 
 
+# round 6: the clock the chip ran at INSIDE the count kernels -- shader cycles (s_memtime) / real time (s_memrealtime, 100 MHz) of the blocks'
+# matrix-core loops, instrumented build (tools/census_count.py, tools/census_filter.py; profiles/<TAG>_count_census.json)
+EFFECTIVE_CLOCK = {}
+_cc = os.path.join(fin, "count_census.json")
+if not os.path.exists(_cc):
+    _cc = os.path.join(ROOT, "profiles", TAG + "_count_census.json")
+if os.path.exists(_cc):
+    _c = json.load(open(_cc))["cases"]
+    for kern, case in (("k_count_bf16<1>", "cfg3_B64_staged_first_launch"), ("side:k_count_bf16<0>", "estimate_4096_full_B64"),
+                       ("side:k_count_bf16<1>", "cfg3_B64_staged_first_launch")):
+        if case in _c and "effective_clock_GHz_mfma_loop" in _c[case]:
+            EFFECTIVE_CLOCK[kern] = {"GHz": round(_c[case]["effective_clock_GHz_mfma_loop"], 3),
+                                     "source": "profiles/%s_count_census.json case %s: s_memtime / s_memrealtime over the matrix-core loops (median call of %d; all calls: %s)"
+                                               % (TAG, case, _c[case].get("calls", 0), _c[case].get("effective_clock_GHz_mfma_loop_all_calls"))}
+_fc = os.path.join(fin, "filter_census.json")
+if not os.path.exists(_fc):
+    _fc = os.path.join(ROOT, "profiles", TAG + "_filter_census.json")
+if os.path.exists(_fc):
+    try:
+        _f = json.load(open(_fc))
+        _g = [c["shader_clock_ghz"] for c in _f.get("cases", []) if isinstance(c, dict) and "shader_clock_ghz" in c]     # (the first case is cfg3 at B = 64)
+        if _g:
+            for k in ("k_count_filter_runs", "side:k_count_filter_runs"):
+                EFFECTIVE_CLOCK[k] = {"GHz": round(_g[0], 3), "source": "profiles/%s_filter_census.json: a block's shader cycles / its lifetime on the 100 MHz counter" % TAG}
+    except Exception as e:                                               # noqa: BLE001
+        print("filter census not usable for the clock:", e)
+
+
 def kernel_block(summary, kern):
     def v(name):
         return summary["pmc"].get(kern, {}).get(name, {}).get("main_mean", 0.0)
@@ -110,6 +138,22 @@ def kernel_block(summary, kern):
            "valu_busy": round(min(1.0, act * 4 / 1024 / (gui / 8)), 4) if gui else None,
            "valu_busy_raw": round(act * 4 / 1024 / (gui / 8), 4) if gui else None,
            "avg_us": summary.get("kernel_stats", {}).get(kern, {}).get("avg_us")}
+    # round 6 (VERDICT r5 #1b): figures that CAN be below 1 and are not instruction counts in another unit -- the share of the resident
+    # waves' cycles (SQ_WAVE_CYCLES, quad-cycles summed over waves) spent waiting for an instruction to issue / complete, and the share
+    # in which the wave had any instruction executing.  valu_busy above is SQ_ACTIVE_INST_VALU x 4 / SIMD cycles: that counter ticks one
+    # quad-cycle per issued VALU instruction (it equals SQ_INSTS_VALU to 1 %), so "busy" = instructions x 4 cycles / time BY CONSTRUCTION --
+    # an issue rate with an assumed 4-cycle cost, not an observation of a busy pipe.  Kept under its old name for continuity.
+    wc = v("SQ_WAVE_CYCLES")
+    if wc:
+        blk.update({"SQ_WAVE_CYCLES": int(wc), "wave_wait_inst_frac": round(v("SQ_WAIT_INST_ANY") / wc, 4) if v("SQ_WAIT_INST_ANY") else None,
+                    "wave_active_inst_frac": round(v("SQ_ACTIVE_INST_ANY") / wc, 4) if v("SQ_ACTIVE_INST_ANY") else None,
+                    "mean_resident_waves_per_simd": round(wc * 4 / 1024 / (gui / 8), 2) if gui else None})
+    clk = EFFECTIVE_CLOCK.get(kern if summary is summ else "side:" + kern)
+    if clk:
+        blk["effective_clock_GHz"] = clk["GHz"]
+        blk["effective_clock_source"] = clk["source"]
+        if blk["avg_us"] and v("SQ_INSTS_VALU"):
+            blk["simd_cycles_per_valu_instruction_at_effective_clock"] = round(blk["avg_us"] * 1e-6 * clk["GHz"] * 1e9 * 1024 / v("SQ_INSTS_VALU"), 3)
     if mfma:      # round 5: the matrix pipe (SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles per v_mfma_f32_32x32x16_bf16, summed over the SIMDs)
         blk.update({"SQ_INSTS_MFMA": int(mfma), "SQ_VALU_MFMA_BUSY_CYCLES": int(mfma_cyc),
                     "mfma_busy": round(mfma_cyc / 1024 / (gui / 8), 4) if gui else None,
@@ -127,6 +171,29 @@ call = {"workload": old.get("workload"), "round": TAG,
                "SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8); gathers and "
                "atomics are taken x1.0, uncalibrated",
         "kernels": {k: kernel_block(summ, k) for k in summ["pmc"]}}
+# round 6: what the loop's own instruction mix can issue -- tools/microbench/count_pipe3.hip (per SIMD, shader cycles per matrix-core tile)
+_p3 = os.path.join(fin, "count_pipe3.txt")
+if not os.path.exists(_p3):
+    _p3 = os.path.join(ROOT, "profiles", TAG + "_count_pipe3.txt")
+if os.path.exists(_p3):
+    rows3 = {}
+    for line in open(_p3):
+        m = re.match(r"(\d) (.*?)\s+W=(\d)\s+([\d.]+) ms \| per wave:\s+([\d.]+) cyc/tile\s+([\d.]+) ns/tile -> ([\d.]+) GHz \| per SIMD:\s+([\d.]+) ns/tile =\s+([\d.]+) cyc/tile", line)
+        if m and (m.group(1), m.group(3)) not in rows3:
+            rows3[(m.group(1), m.group(3))] = {"label": m.group(2).strip(), "waves_per_simd": int(m.group(3)), "ms": float(m.group(4)), "GHz": float(m.group(7)),
+                                               "ns_per_tile_and_simd": float(m.group(8)), "cycles_per_tile_and_simd": float(m.group(9))}
+    if ("0", "5") in rows3 and ("8", "5") in rows3 and ("5", "5") in rows3:
+        VPT = 21.75                                                      # VALU instructions per tile in the loop's listing (174 per 8 tiles)
+        call["count_loop_microbench"] = {
+            "source": "profiles/%s_count_pipe3.txt (tools/microbench/count_pipe3.hip): the kernel's per-tile loop alone, 5 waves per SIMD, 60 ms pre-warm; "
+                      "per SIMD = kernel time by HIP events / tiles per SIMD, converted with the clock measured inside the loop (s_memtime / s_memrealtime)" % TAG,
+            "valu_instructions_per_tile": VPT,
+            "shipped_loop": rows3[("0", "5")], "valu_alone": rows3[("8", "5")], "mfma_alone": rows3[("5", "5")],
+            "calibration_one_wave_per_simd_mfma_alone": rows3.get(("5", "1")),
+            "knock_outs": {k: rows3[(k, "5")] for k in ("6", "7", "1") if (k, "5") in rows3},
+            "occupancy": {w: rows3[("0", w)] for w in ("4", "6", "8") if ("0", w) in rows3},
+            "simd_cycles_per_valu_instruction_valu_alone": round(rows3[("8", "5")]["cycles_per_tile_and_simd"] / VPT, 3),
+            "simd_cycles_per_valu_instruction_with_mfma": round(rows3[("0", "5")]["cycles_per_tile_and_simd"] / VPT, 3)}
 side_path = os.path.join(fin, "prof_side_summary.json")
 if os.path.exists(side_path):
     side = json.load(open(side_path))
@@ -136,7 +203,8 @@ if os.path.exists(side_path):
                                      command="python tools/prof_side.py")
     call["decode_fused"] = {k: kernel_block(side, k) for k in ("k_tile_scan_seg2", "k_mask_from_lists") if k in side.get("pmc", {})}
 json.dump(call, open(os.path.join(ROOT, "profiles", "call_pmc.json"), "w"), indent=1)
-for extra_name in ("staged_ab.json", "staged_ab_outliers.json", "ab_filter_runs.txt", "auto_regret.json", "filter_census.json", "count_pipe2.txt"):
+for extra_name in ("staged_ab.json", "staged_ab_outliers.json", "ab_filter_runs.txt", "auto_regret.json", "filter_census.json", "count_pipe2.txt",
+                   "count_census.json", "count_pipe3.txt"):
     if os.path.exists(os.path.join(fin, extra_name)):
         import shutil
         shutil.copy(os.path.join(fin, extra_name), os.path.join(ROOT, "profiles", TAG + "_" + extra_name))
