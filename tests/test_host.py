@@ -203,14 +203,15 @@ def test_reference_pin_is_built():
 
 
 def test_bench_line_contract_on_the_committed_evidence():
-    """The JSON line bench.py printed on the MI355X (profiles/r05_bench_default.json; r05_bench_torchrun_1rank.json is the same
+    """The JSON line bench.py printed on the MI355X (profiles/r06_bench_default.json; r06_bench_torchrun_1rank.json is the same
     command under torch.distributed.run with a one-rank RCCL group) carries every field of the driver's contract, the
-    BASELINE.json metric, round 5's roofline block -- the dominant pass against VALU issue, reproducible by hand from the tracked
-    rocprofv3 summaries -- beside the dense-read equivalent, every `frac` bounded by 1, and numbers consistent with each other."""
+    BASELINE.json metric, the roofline block -- the dominant pass against VALU issue, reproducible by hand from the tracked
+    rocprofv3 summaries, since round 6 also against the clock measured INSIDE the kernels and against the measured issue ceiling of the
+    loop's own instruction mix -- beside the dense-read equivalent, every `frac` bounded by 1, and numbers consistent with each other."""
     import csv
     import json
-    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
-    tr = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_torchrun_1rank.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_default.json")))
+    tr = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_torchrun_1rank.json")))
     pmc = json.load(open(os.path.join(ROOT, "profiles", "call_pmc.json")))
     assert tr["extra"]["rccl_ranks"] == 1 and "all_gather" in tr["extra"]["exchange"] and tr["n_gpus"] == 1
     assert tr["extra"]["exchange_impl"].startswith("rccl")                                       # ncclAllGather on the launch stream
@@ -231,7 +232,7 @@ def test_bench_line_contract_on_the_committed_evidence():
     second = "k_count_filter_runs"
     passk = ["k_count_bf16<1>", "k_lead", second]
     call = ["k_tile_scan", "k_compact_hyp"] + passk + ["k_select_refit", "k_finalize_v3"]
-    assert pmc["workload"] == "cfg3_B64" and pmc["round"] == "r05" and all(n in pmc["kernels"] for n in call)
+    assert pmc["workload"] == "cfg3_B64" and pmc["round"] == "r06" and all(n in pmc["kernels"] for n in call)
     # ---- THE roofline block: the dominant pass (the inlier count) against the resource that binds it, VALU issue
     r = line["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -244,7 +245,22 @@ def test_bench_line_contract_on_the_committed_evidence():
     mfma = sum(pmc["kernels"][n].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for n in passk)
     gui = sum(pmc["kernels"][n]["GRBM_GUI_ACTIVE"] for n in passk)
     assert abs(r["mfma_busy_frac"] - mfma / 1024 / (gui / 8)) < 1e-3 and 0.05 < r["mfma_busy_frac"] < 0.3   # the matrix pipe idles
-    assert 0 < r["busy_frac_counter"] < 1
+    assert 0 < r["busy_frac_counter"] < 1 and "NOT independent evidence" in r["busy_frac_counter_note"]
+    # round 6: the same fraction at the clock stamped inside the kernels, and against the loop's own measured ceiling
+    clk = {n: pmc["kernels"][n].get("effective_clock_GHz") for n in passk}
+    assert 1.8 < clk["k_count_bf16<1>"] < 2.4 and 1.8 < clk["k_count_filter_runs"] < 2.4 and "s_memrealtime" in pmc["kernels"]["k_count_bf16<1>"]["effective_clock_source"]
+    assert min(v for v in clk.values() if v) <= r["effective_clock_GHz"] <= max(v for v in clk.values() if v)
+    assert abs(r["frac_at_effective_clock"] - r["frac"] * 2.4 / r["effective_clock_GHz"]) < 3e-3 and r["frac"] < r["frac_at_effective_clock"] < 1
+    mb = pmc["count_loop_microbench"]
+    assert 30 < mb["mfma_alone"]["cycles_per_tile_and_simd"] < 38                               # the matrix pipe's 32 cycles: s_memtime is the shader clock
+    assert mb["valu_alone"]["cycles_per_tile_and_simd"] < mb["shipped_loop"]["cycles_per_tile_and_simd"] < mb["valu_alone"]["cycles_per_tile_and_simd"] + mb["mfma_alone"]["cycles_per_tile_and_simd"]
+    assert 2.0 < mb["simd_cycles_per_valu_instruction_valu_alone"] < mb["simd_cycles_per_valu_instruction_with_mfma"] < 5.0
+    assert all(abs(k_["cycles_per_tile_and_simd"] / mb["shipped_loop"]["cycles_per_tile_and_simd"] - 1) < 0.05 for k_ in (mb["knock_outs"]["6"], mb["knock_outs"]["7"]))   # no knock-out wins
+    fm = r["frac_of_measured_mix_roof"]
+    assert abs(fm["valu_alone"] - r["frac_at_effective_clock"] * mb["simd_cycles_per_valu_instruction_valu_alone"] / 2.0) < 3e-3 and fm["valu_alone"] < fm["beside_the_mfma"] <= 1
+    assert all(0.1 < v < 0.6 for v in r["wave_wait_inst_frac_per_kernel"].values())
+    e4 = pmc["estimate_4096"]
+    assert 1.8 < e4["effective_clock_GHz"] < 2.4 and 3.0 < e4["simd_cycles_per_valu_instruction_at_effective_clock"] < 4.2
     # ---- the dense-read equivalent (the contract's HBM view, whole call), bounded, with the counter-backed traffic of all its kernels
     de = line["roofline_dense_equivalent"]
     assert de["bound"].startswith("hbm") and de["unit"] == "GB/s" and abs(de["frac"] - de["achieved"] / de["peak"]) < 1e-3 and 0 < de["frac"] <= 1
@@ -255,7 +271,7 @@ def test_bench_line_contract_on_the_committed_evidence():
     assert r["hbm_view"]["dense_equivalent_frac"] == de["frac"]
     # ---- the count pass: events inside calls agree with the tracked rocprofv3 averages of its kernels (same box, another process)
     c = line["roofline_contract_count_pass"]
-    ks = {row["Name"]: float(row["AverageNs"]) / 1e6 for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_kernel_stats.csv")))}
+    ks = {row["Name"]: float(row["AverageNs"]) / 1e6 for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_kernel_stats.csv")))}
     prof = ks["k_count_bf16<1>"] + ks["k_lead"] + ks[second]
     assert abs(c["kernel_ms_avg"] - prof) / prof < 0.08, (c["kernel_ms_avg"], prof)
     assert prof < 0.116                                                                          # round 4: 0.1187 (the filter kernel at four blocks per CU)
@@ -275,7 +291,12 @@ def test_bench_line_contract_on_the_committed_evidence():
         assert key in cb, key
     assert cb["kind"] in ("port", "reference") and cb["unit"] == line["unit"] and cb["single_thread"]["cores"] == 1
     assert cb["thread_probe"]["picked"] == cb["cores"] and len(cb["thread_probe"]["table"]) >= 3
-    picked = [t for t in cb["thread_probe"]["table"] if t["threads"] == cb["cores"]][0]
+    picked = [t for t in cb["thread_probe"]["table"] if t["threads"] == cb["cores"] and t["form"] == cb["form"]][0]
+    # round 6: both forms timed, the quota visible
+    assert {t["form"] for t in cb["thread_probe"]["table"]} == {"hypothesis_parallel", "image_parallel"} and cb["form"] in ("hypothesis_parallel", "image_parallel")
+    assert "cgroup_cpu_quota" in cb and cb["sched_getaffinity_count"] == cb["usable_cpus"]
+    assert cb["cgroup_quota_cpus"] is None or cb["cores"] <= 4 * cb["cgroup_quota_cpus"]
+    assert cb["value"] >= max(t["images_per_s_median"] for t in cb["thread_probe"]["table"]) - 0.01
     assert picked["images_per_s_median"] == round(cb["value"], 2) and cb["spread"]["repetitions"] >= 3
     assert cb["spread"]["min"] <= cb["value"] <= cb["spread"]["max"] and cb["spread"]["max"] / cb["spread"]["min"] < 1.1
     assert "numpy" not in cb["sample"] and "in C" in cb["sample"]
@@ -300,6 +321,10 @@ def test_bench_line_contract_on_the_committed_evidence():
     assert e["decode_fused_mask_equals_torch_argmax"] is True and e["decode_fused_vs_headline"] >= 0.95
     assert e["decode_fused_images_per_s"] > e["decode_unfused_argmax_plus_v3_images_per_s"]
     assert "UNMEASURED" in e["predicted_8gpu"]["source"] and e["predicted_8gpu"]["exchange_ms"] < 0.005
+    assert e["predicted_8gpu"]["inputs"]["shard_of_8"] == "cfg3_B8_shard_of_8gpu" and e["predicted_8gpu"]["inputs"]["file"] == "profiles/r06_configs.json"
+    # the N > 1 block at the top level (VERDICT r5 #2c): present on the one-rank RCCL line, absent without a process group
+    assert line["multi_gpu"] is None and tr["multi_gpu"]["exchange_impl"] == "rccl_direct" and tr["multi_gpu"]["rccl_ranks"] == 1
+    assert tr["multi_gpu"]["shard_sizes"] == [64] and len(tr["multi_gpu"]["per_rank_count_pass_ms"]) == 1
 
 
 def test_bare_bench_gpus_n_builds_the_torchrun_command(monkeypatch):
