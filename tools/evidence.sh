@@ -1,6 +1,10 @@
 #!/bin/bash
 # One gpurun call that produces everything tools/refresh_profiles.py copies into profiles/ for a round:
 #   gpurun --timeout 1500 -- 'bash tools/evidence.sh r2f'     then     python tools/refresh_profiles.py gpurun_out/prof_r2f gpurun_out/r2f r02
+# Build BEFORE the call, in the container (hipcc cross-compiles; the artefacts travel with the snapshot):
+#   tools/build_variant.sh stamps -DPVV_TUNING -DPVV_STAMPS          # census_filter.py, census_count.py
+#   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form tools/microbench/count_pipe3.hip -o build/mb/cp3
+#   (same flags) tools/microbench/count_pipe2.hip -o build/mb/cp2    # round 5's version, kept for continuity
 set -u
 TAG=${1:-ev}
 OUT=$PWD/gpurun_out/$TAG
