@@ -61,10 +61,12 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy reaches
 # VALU issue: 1024 SIMDs; a wave64 VALU instruction occupies its SIMD for 2 cycles at full rate (MI355X_MICROARCH.md's
-# table; confirmed in round 4 with true shader-clock counts, tools/microbench/valu_rate3.hip -> profiles/r04_microbench.txt:
-# v_fma / v_mul / v_add / v_sub 1.3-2.1 cycles at 8 waves per SIMD, 2.4-2.9 at 4; v_alignbit / v_min3 / v_cmp / v_pk_fma are
-# half rate, 2.6-4.3.  Round 1's "4.2 cycles" divided event times by an ASSUMED 2.4 GHz while the chip ran the all-FMA
-# test at ~1.55 GHz, and used too few waves).  The ceiling below is the full-rate one at the device's max clock.
+# table: reached by v_fma / v_mul / v_add / v_sub at 8 waves per SIMD of nothing else, tools/microbench/valu_rate3.hip ->
+# profiles/r04_microbench.txt).  The ceiling below is that full-rate one at the device's max clock -- the contract's roof.  What the
+# count loop's OWN instruction mix can issue at the kernel's occupancy, and the clock the chip really runs at inside the kernels, are
+# measured (round 6: tools/microbench/count_pipe3.hip, tools/census_count.py -> profiles/call_pmc.json) and reported beside it as
+# roofline.frac_at_effective_clock and roofline.frac_of_measured_mix_roof.  (The "GHz implied" of the older microbenchmarks -- wave
+# cycles / kernel time -- is a lower bound, not the clock: waves of one SIMD finish far apart.)
 # VALU_PER_TILE: one 16-pixel x 32-hypothesis matrix-core tile (512 evaluations) costs 21 VALU in the steady-state loop.
 VALU_PER_TILE, CYCLES_PER_VALU, N_SIMD, EVALS_PER_TILE = 21, 2.0, 1024, 512
 
