@@ -230,8 +230,9 @@ def test_bench_one_rank_rccl_group_survives_an_injected_communicator_fault(gpu, 
     """PVV_RCCL_FAULT=0:<stage> under a REAL one-rank RCCL group (the rehearsal hook of clean_pvnet_amd/rccl.py): the direct
     communicator is given up, the step's exchange goes through torch.distributed's collective, the line says why, rc 0."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
-           "--batch", "4", "--rotate", "2", "--no-cpu-baseline", "--no-sustained", "--no-side-legs", "--no-two-stream"]
+           "--master-port", str(29537 + ["load", "before_init", "inside_init"].index(stage)), os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "4", "--rotate", "2", "--no-cpu-baseline", "--no-sustained",
+           "--no-side-legs", "--no-two-stream"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=dict(_env(), PVV_RCCL_FAULT="0:" + stage), timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
