@@ -53,6 +53,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) voi
     }
     const long long r0 = wall_clock64();
     const long long t0 = (long long)__builtin_readcyclecounter();
+    if (MODE == 10) {
+        // mode 10: the shipped VALU work, software-pipelined inside the wave -- the MFMA of tile j + 1 is issued BEFORE the 21 VALU
+        // instructions that consume tile j (two accumulator sets: +16 VGPRs), so that a wave never waits on its own MFMA
+        float16v cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bop, zero16, 0, 0, 0);
+        for (int it = 0; it < ITERS; ++it) {
+            unsigned flagged = 0;
+            unsigned qs[2] = {0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float16v nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(j + 1) & 7], Bop, zero16, 0, 0, 0);
+                asm volatile("" ::: "memory");
+                float tmin = INFINITY;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = cur[e] - fabsf(cur[8 + e]);
+                    qs[j >> 2] = __builtin_amdgcn_alignbit(qs[j >> 2], __float_as_uint(t), 31);
+                    tmin = fminf(tmin, fabsf(t));
+                }
+                if (__ballot(tmin <= Wb) != 0) flagged |= 1u << j;
+                cur = nxt;
+            }
+            total += 64 - __popc(qs[0]) - __popc(qs[1]);
+            flagged_any |= flagged;
+            asm volatile("" : "+v"(Bop));
+        }
+        total += (int)cur[0];
+    } else
 #pragma unroll 1
     for (int it = 0; it < ITERS; ++it) {
         unsigned flagged = 0;
@@ -161,6 +188,8 @@ int main()
     run(tile_kernel<5, 5>, "5 MFMA alone", 5, d, dst);
     run(tile_kernel<8, 5>, "8 VALU of the shipped loop alone (21, no MFMA)", 5, d, dst);
     run(tile_kernel<0, 5>, "0 shipped (8 sub|abs|, 8 alignbit, 4 min3, cmp)", 5, d, dst);
+    run(tile_kernel<10, 5>, "10 shipped VALU, MFMA of the NEXT tile issued first (2 acc sets)", 5, d, dst);
+    run(tile_kernel<10, 4>, "10 the same at FOUR waves per SIMD (its 112-VGPR budget)", 4, d, dst);
     run(tile_kernel<6, 5>, "6 knock-out: v_sub as VOP2, no |abs| modifier", 5, d, dst);
     run(tile_kernel<7, 5>, "7 knock-out: two independent sign queues", 5, d, dst);
     run(tile_kernel<3, 5>, "3 without the sign queue (8 sub, 8 or, 4 min3, cmp)", 5, d, dst);
